@@ -1,0 +1,186 @@
+/*
+ * mi355rt.h -- C ABI of libmi355rt.so, the MI355X (gfx950) implementation of the per-pixel trace
+ * loop of sranger/Ray-Tracer.
+ *
+ * The reference has no plugin / FFI interface; the seam is the body of
+ * Camera.createImage() (Camera.java:119-185).  Every entry point below names the reference
+ * code it replaces; paths are relative to /root/reference/src/stephen/ranger/ar/.
+ *
+ * Conventions: plain C, POD structs, no C++ or torch types.  Every function returns 0 on success
+ * or a negative MI355RT_E_* code; the message is available from mi355rt_last_error() (thread
+ * local).  Callers own every buffer they pass; the library copies inputs during scene_create and
+ * keeps no caller pointer past a call.  There is no CPU fallback: without a HIP device every
+ * compute entry point fails with MI355RT_E_DEVICE.
+ */
+#ifndef MI355RT_H
+#define MI355RT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355RT_ABI_VERSION 1
+
+enum {
+   MI355RT_OK = 0,
+   MI355RT_E_ARG = -1,      /* bad argument (null pointer, negative size, index out of range) */
+   MI355RT_E_DEVICE = -2,   /* no HIP device / HIP runtime error */
+   MI355RT_E_MEMORY = -3,   /* host or device allocation failed */
+   MI355RT_E_LIMIT = -4,    /* a documented limit was exceeded (tree depth, scratch size ...) */
+   MI355RT_E_IO = -5        /* PLY file unreadable or malformed */
+};
+
+/* materials/ColorInformation.java:15-37, materials/BRDFMaterial.java:47-51,158-167,
+ * materials/ReflectionMaterial.java:10-24 */
+enum { MI355RT_MAT_COLOR = 0, MI355RT_MAT_BRDF = 1, MI355RT_MAT_REFLECTION = 2 };
+/* lighting/LightingModel.java:13-15 (0), lighting/PhongLightingModel.java:18-54 (1) */
+enum { MI355RT_LIGHTING_PLAIN = 0, MI355RT_LIGHTING_PHONG = 1 };
+
+typedef struct {
+   uint32_t kind;
+   float emission[3], ambient[3], diffuse[3], specular[3]; /* Color.getColorComponents() values */
+   float shininess;                                        /* 20 by default, 100 for ReflectionMaterial */
+   int32_t brdf_id;                                        /* row of the weights table (BRDFMaterial.java:50) */
+} mi355rt_material;
+
+/* the three arrays TriangleMesh hands to KDTree (sceneObjects/TriangleMesh.java:19-21,89), flattened */
+typedef struct {
+   const float *vertices;  /* n_vertices * 3 */
+   const float *normals;   /* n_vertices * 3, or NULL: synthesised as TriangleMesh.computeNormals (:96-126) */
+   const int32_t *indices; /* n_faces * 3 */
+   uint32_t n_vertices, n_faces;
+   mi355rt_material material;
+} mi355rt_mesh_desc;
+
+typedef struct {
+   int32_t max_depth;    /* RTStatics.MAX_DEPTH = 20    (RTStatics.java:25) */
+   int32_t max_children; /* RTStatics.MAX_CHILDREN = 5  (RTStatics.java:24) */
+   int32_t use_kdtree;   /* the GUI's KD-tree checkbox / computeKDTree (bounds/KDNode.java:40) */
+   int32_t device;       /* HIP device ordinal; -1 = the calling thread's current device */
+} mi355rt_build_opts;
+
+/* what the Camera constructor derives (Camera.java:40-94) */
+typedef struct {
+   float origin[3];
+   float rotation[9]; /* row-major 3x3 of Camera.rotation (m00 m01 m02 m10 ...) */
+   float viewport_w, viewport_h, near_plane;
+   int32_t width, height;
+} mi355rt_camera;
+
+/* RTStatics settings + Camera/Scene fields that stay on the Java side and are passed per render */
+typedef struct {
+   float epsilon;               /* RTStatics.EPSILON as set by the Scene ctor (Scene.java:35-36) */
+   float near_plane, far_plane; /* RTStatics.NEAR_PLANE 0.01f / FAR_PLANE 3000f (RTStatics.java:19-20) */
+   int32_t max_recursion_depth; /* RTStatics.MAX_RECURSION_DEPTH (unused by mesh objects: KDTree.getColor has no cut-off) */
+   int32_t multi_samples;       /* Camera.multiSamples */
+   int32_t brdf_samples;        /* Camera.brdfSamples */
+   int32_t lighting_model;      /* MI355RT_LIGHTING_* */
+   int32_t max_mirror_bounces;  /* guard where the reference would recurse without bound (bounds/KDTree.java:77-80) */
+   uint64_t rng_seed;           /* the reference's jitter RNG is unseeded (RenderThread.java:32); see DESIGN.md */
+   float light_origin[3], light_emission[3], light_ambient[3]; /* lighting/Light.java:7-16 */
+   int32_t tile_size;           /* image-tile sharding: square tiles of this many pixels (multiple of 8; 0 = 16) */
+   int32_t tile_rank, tile_world; /* this process renders tiles t with t % tile_world == tile_rank */
+   int32_t collect_stats;       /* non-zero: count rays / box tests / triangle tests (slower; see mi355rt_frame_stats) */
+} mi355rt_settings;
+
+typedef struct {
+   uint64_t primary_rays, shadow_rays, secondary_rays;
+   uint64_t box_tests, tri_tests, hits;
+} mi355rt_stats;
+
+/* device-resident frame outputs; any pointer may be NULL.  Pixel p = y*width + x (row-major);
+ * Camera.pixels[x][y] is the transpose. */
+typedef struct {
+   float *rgb;        /* width*height*3, unclamped f32 after the NaN scrub (Camera.java:96-101) */
+   uint32_t *argb8;   /* width*height, Color(r,g,b).getRGB() as in Camera.image (Camera.java:103-107) */
+   int32_t *hit_id;   /* width*height, face index within its mesh for sample 0, -1 = miss */
+   int32_t *hit_obj;  /* width*height, mesh index for sample 0, -1 = miss */
+   float *hit_w;      /* width*height, IntersectionInformation.w for sample 0 */
+} mi355rt_frame;
+
+typedef struct mi355rt_scene mi355rt_scene;
+
+/* ---- scene ------------------------------------------------------------------------------- */
+
+/* Replaces `new KDTree(mesh, vertices, normals, indices, colorInfo, computeKDTree)` per mesh
+ * (bounds/KDTree.java:24-56, bounds/KDNode.java:29-90) and `new Scene(volumes, ...)`'s bounds
+ * (Scene.java:21-33): builds the reference's hierarchy, flattens it and uploads it to HBM. */
+int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts,
+                         mi355rt_scene **out);
+void mi355rt_scene_destroy(mi355rt_scene *scene);
+
+/* Replaces BRDFMaterial.brdfDirections / brdfWeights (materials/BRDFMaterial.java:33,43): takes the
+ * PARSED tables (rows of table.txt: theta_v phi_v theta_i phi_i; rows of abrdf.dat) and applies
+ * BRDFMaterial.remapDirections (:148-156, PBRTMath.java:74-97). */
+int mi355rt_brdf_tables(mi355rt_scene *scene, const float *angles_nx4, int32_t n_dirs, const float *weights,
+                        int32_t n_materials);
+
+/* Scene ctor's RTStatics.EPSILON choice (Scene.java:35-36) for this scene's bounds. */
+int mi355rt_scene_epsilon(const mi355rt_scene *scene, float *epsilon_out);
+
+/* object i: minmax = {minx,miny,minz,maxx,maxy,maxz} (KDTree.getMinMax), KDTree.shadowDistance,
+ * and sizes of the flattened hierarchy. */
+int mi355rt_scene_object_info(const mi355rt_scene *scene, uint32_t object, float minmax[6], float *shadow_distance,
+                              uint64_t *n_nodes, uint64_t *n_leaves, uint64_t *n_leaf_slots, int32_t *max_depth);
+/* bytes of HBM held by the scene */
+int mi355rt_scene_device_bytes(const mi355rt_scene *scene, uint64_t *bytes_out);
+
+/* Replaces the Camera constructor's derived fields (Camera.java:50-51,56-57,59-81,
+ * RTStatics.initializeQuat4f RTStatics.java:345-361).  A Java caller may instead fill
+ * mi355rt_camera from its own Camera object. */
+int mi355rt_camera_setup(const mi355rt_scene *scene, const float orientation_deg[3], float fov_deg, float near_plane,
+                         int32_t width, int32_t height, mi355rt_camera *out);
+
+/* ---- render ------------------------------------------------------------------------------ */
+
+/* Replaces Camera.createImage() + RenderThread.run() + Camera.setPixel() (Camera.java:119-185,
+ * RenderThread.java:30-69, Camera.java:96-108): blocking; host output buffers (any may be NULL):
+ * rgb W*H*3 f32 row-major, hit_id / hit_w W*H for sample 0. */
+int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
+                   int32_t *hit_id_out, float *hit_w_out);
+
+/* Same frame, outputs left in device memory (pointers in `frame` are device pointers on the
+ * scene's device).  Asynchronous on `hip_stream` (a hipStream_t, NULL = the null stream); the
+ * caller synchronises.  With tile_world > 1 only this rank's tiles are written. */
+int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings,
+                          const mi355rt_frame *frame, void *hip_stream);
+
+/* Counters of the most recent render on this scene that ran with settings.collect_stats != 0
+ * (blocking: synchronises the scene's device). */
+int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out);
+
+/* Camera.getClosestIntersection(null, origin, direction, null, 0) for a batch of rays
+ * (Camera.java:193-215): host buffers, n*3 origins / directions in; any output may be NULL. */
+int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, uint64_t n, const float *origins,
+                       const float *directions, int32_t *hit_id, int32_t *hit_obj, float *hit_w, float *hit_point,
+                       float *hit_normal);
+
+/* ---- loader (next row: SURVEY.md 8f rank 1) ---------------------------------------------- */
+
+/* Replaces the TriangleMesh constructor's parse (sceneObjects/TriangleMesh.java:23-94,128-197).
+ * Arrays are malloc'ed by the library; release each with mi355rt_free. */
+int mi355rt_ply_load(const char *path, uint32_t *n_vertices, uint32_t *n_faces, float **vertices, float **normals,
+                     int32_t **indices, int32_t *has_normals);
+/* TriangleMesh.computeNormals (sceneObjects/TriangleMesh.java:96-126) into normals_out (n_vertices*3). */
+int mi355rt_compute_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces,
+                            float *normals_out);
+void mi355rt_free(void *p);
+
+/* ---- misc -------------------------------------------------------------------------------- */
+
+/* Diagnostic: evaluates on the device the arithmetic primitives bit-exact parity rests on, per element:
+ * a/b (f32), sqrt(a) (f32), (float)(1.0/sqrt((double)a)) (Vector3f.normalize's scale) and
+ * (float)pow((double)b, 20.0) (the Phong exponent).  No counterpart in the reference. */
+int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_div, float *out_sqrt, float *out_rnorm,
+                        float *out_pow);
+
+const char *mi355rt_last_error(void);
+int mi355rt_abi_version(void);
+int mi355rt_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

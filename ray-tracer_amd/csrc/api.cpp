@@ -1,0 +1,642 @@
+// api.cpp -- the C ABI of libmi355rt.so (include/mi355rt.h): handles, error reporting, host-side
+// set-up (camera constants, BRDF table remap) and HIP memory / launch plumbing.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355rt.h"
+#include "host_math.hpp"
+#include "kernels.h"
+#include "layout.h"
+#include "ply_reader.hpp"
+#include "scene_build.hpp"
+
+using namespace mi355rt;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg)
+{
+   g_error = msg;
+   return code;
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+   return fail(e == hipErrorOutOfMemory ? MI355RT_E_MEMORY : MI355RT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+   do {                                                \
+      hipError_t e_ = (expr);                          \
+      if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+   } while (0)
+
+// makes `device` current for the scope of one API call
+class DeviceScope {
+ public:
+   explicit DeviceScope(int device) : prev_(-1), ok_(true)
+   {
+      if (hipGetDevice(&prev_) != hipSuccess) { ok_ = false; return; }
+      if (prev_ != device && hipSetDevice(device) != hipSuccess) ok_ = false;
+      changed_ = ok_ && prev_ != device;
+   }
+   ~DeviceScope()
+   {
+      if (changed_) (void) hipSetDevice(prev_);
+   }
+   bool ok() const { return ok_; }
+
+ private:
+   int prev_;
+   bool ok_;
+   bool changed_ = false;
+};
+
+struct HostObject {
+   float bmin[3], bmax[3];
+   float shadow_distance;
+   uint64_t n_nodes, n_leaves, n_slots;
+   int32_t max_depth;
+   void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;
+};
+
+}   // namespace
+
+struct mi355rt_scene {
+   int device = 0;
+   std::vector<HostObject> objects;
+   std::vector<mi355rt_material> materials;
+   DevObject *d_objs = nullptr;
+   float *d_brdf_dirs = nullptr, *d_brdf_weights = nullptr;
+   int32_t n_dirs = 0, n_materials = 0;
+   float smin[3], smax[3];   // scene bounds (Scene.java:21-33)
+   float abs_max = 0.f;
+   uint64_t device_bytes = 0;
+   unsigned long long *d_stats = nullptr;   // 6 counters
+   bool stats_valid = false;
+   // scratch frame for the host-buffer render entry point
+   float *d_rgb = nullptr;
+   int32_t *d_hit_id = nullptr;
+   float *d_hit_w = nullptr;
+   size_t scratch_pixels = 0;
+};
+
+namespace {
+
+void release_scene(mi355rt_scene *s)
+{
+   if (!s) return;
+   for (HostObject &o : s->objects) {
+      if (o.d_nodes) (void) hipFree(o.d_nodes);
+      if (o.d_tris) (void) hipFree(o.d_tris);
+      if (o.d_fnrm) (void) hipFree(o.d_fnrm);
+   }
+   if (s->d_objs) (void) hipFree(s->d_objs);
+   if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
+   if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
+   if (s->d_stats) (void) hipFree(s->d_stats);
+   if (s->d_rgb) (void) hipFree(s->d_rgb);
+   if (s->d_hit_id) (void) hipFree(s->d_hit_id);
+   if (s->d_hit_w) (void) hipFree(s->d_hit_w);
+   delete s;
+}
+
+int upload(const void *src, size_t bytes, void **dst, mi355rt_scene *s)
+{
+   *dst = nullptr;
+   const size_t alloc = bytes ? bytes : 64;
+   HIP_TRY(hipMalloc(dst, alloc));
+   s->device_bytes += alloc;
+   if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+   return MI355RT_OK;
+}
+
+int check_settings(const mi355rt_settings *st)
+{
+   if (!st) return fail(MI355RT_E_ARG, "settings is null");
+   if (st->multi_samples < 1) return fail(MI355RT_E_ARG, "multi_samples must be >= 1");
+   if (st->brdf_samples < 0) return fail(MI355RT_E_ARG, "brdf_samples must be >= 0");
+   if (st->lighting_model != MI355RT_LIGHTING_PLAIN && st->lighting_model != MI355RT_LIGHTING_PHONG)
+      return fail(MI355RT_E_ARG, "unknown lighting_model");
+   if (st->max_mirror_bounces < 0) return fail(MI355RT_E_ARG, "max_mirror_bounces must be >= 0");
+   return MI355RT_OK;
+}
+
+int fill_render_params(const mi355rt_scene *s, const mi355rt_camera *cam, const mi355rt_settings *st, RenderParams &p)
+{
+   if (!cam) return fail(MI355RT_E_ARG, "camera is null");
+   if (int rc = check_settings(st)) return rc;
+   if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+   if ((uint64_t) cam->width * (uint64_t) cam->height > (uint64_t) 1 << 30) return fail(MI355RT_E_LIMIT, "image larger than 2^30 pixels");
+   std::memset(&p, 0, sizeof(p));
+   std::memcpy(p.origin, cam->origin, sizeof(p.origin));
+   std::memcpy(p.rot, cam->rotation, sizeof(p.rot));
+   // Camera.createImage constants (Camera.java:123-126)
+   p.x_min = -(cam->viewport_w / 2.0f);
+   p.y_min = cam->viewport_h / 2.0f;
+   p.x_inc = cam->viewport_w / (float) cam->width;
+   p.y_inc = -cam->viewport_h / (float) cam->height;
+   p.near_plane_cam = cam->near_plane;
+   p.width = cam->width;
+   p.height = cam->height;
+   p.epsilon = st->epsilon;
+   p.near_plane = st->near_plane;
+   p.far_plane = st->far_plane;
+   p.multi_samples = st->multi_samples;
+   p.brdf_samples = st->brdf_samples;
+   p.lighting_model = st->lighting_model;
+   p.max_mirror_bounces = st->max_mirror_bounces;
+   p.rng_seed = st->rng_seed;
+   std::memcpy(p.light_origin, st->light_origin, sizeof(p.light_origin));
+   std::memcpy(p.light_emission, st->light_emission, sizeof(p.light_emission));
+   std::memcpy(p.light_ambient, st->light_ambient, sizeof(p.light_ambient));
+   p.n_objs = (int32_t) s->objects.size();
+   p.objs = s->d_objs;
+   p.brdf_dirs = s->d_brdf_dirs;
+   p.brdf_weights = s->d_brdf_weights;
+   p.n_dirs = s->n_dirs;
+   p.n_materials = s->n_materials;
+   p.scene_abs_max = s->abs_max;
+   for (size_t i = 0; i < s->materials.size(); i++) {
+      const mi355rt_material &m = s->materials[i];
+      if (m.kind == MI355RT_MAT_BRDF && (m.brdf_id < 0 || m.brdf_id >= s->n_materials))
+         return fail(MI355RT_E_ARG, "mesh " + std::to_string(i) + ": BRDF material row " + std::to_string(m.brdf_id) + " is outside the loaded tables (call mi355rt_brdf_tables first)");
+   }
+
+   int tile = st->tile_size == 0 ? 16 : st->tile_size;
+   int world = st->tile_world == 0 ? 1 : st->tile_world;
+   if (tile < 8 || tile % 8 != 0 || tile > 4096) return fail(MI355RT_E_ARG, "tile_size must be a multiple of 8 in [8, 4096]");
+   if (world < 1 || st->tile_rank < 0 || st->tile_rank >= world) return fail(MI355RT_E_ARG, "need 0 <= tile_rank < tile_world");
+   p.tile_size = tile;
+   p.tile_rank = st->tile_rank;
+   p.tile_world = world;
+   p.tiles_x = (cam->width + tile - 1) / tile;
+   p.tiles_y = (cam->height + tile - 1) / tile;
+   const long long n_tiles = (long long) p.tiles_x * p.tiles_y;
+   const long long owned = n_tiles > st->tile_rank ? (n_tiles - st->tile_rank + world - 1) / world : 0;
+   p.n_owned_tiles = (int32_t) owned;
+   p.micro_per_tile = (tile / 8) * (tile / 8);
+   const long long n_micro = owned * p.micro_per_tile;
+   if (n_micro > 0x7fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups for one launch");
+   p.n_micro = (int32_t) n_micro;
+   return MI355RT_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+const char *mi355rt_last_error(void) { return g_error.c_str(); }
+int mi355rt_abi_version(void) { return MI355RT_ABI_VERSION; }
+
+int mi355rt_device_count(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts, mi355rt_scene **out)
+{
+   if (!out) return fail(MI355RT_E_ARG, "out is null");
+   *out = nullptr;
+   if (!opts) return fail(MI355RT_E_ARG, "build options are null");
+   if (n_meshes && !meshes) return fail(MI355RT_E_ARG, "meshes is null");
+   if (n_meshes > (uint32_t) MAX_OBJECTS) return fail(MI355RT_E_LIMIT, "more than " + std::to_string(MAX_OBJECTS) + " meshes");
+   for (uint32_t i = 0; i < n_meshes; i++) {
+      if (meshes[i].material.kind > MI355RT_MAT_REFLECTION) return fail(MI355RT_E_ARG, "unknown material kind on mesh " + std::to_string(i));
+   }
+   int n_dev = 0;
+   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
+   int device = opts->device;
+   if (device < 0) {
+      if (hipGetDevice(&device) != hipSuccess) return fail(MI355RT_E_DEVICE, "hipGetDevice failed");
+   }
+   if (device >= n_dev) return fail(MI355RT_E_ARG, "device ordinal out of range");
+   DeviceScope scope(device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+
+   BuildOptions bo;
+   bo.max_depth = opts->max_depth;
+   bo.max_children = opts->max_children;
+   bo.use_kdtree = opts->use_kdtree != 0;
+
+   mi355rt_scene *s = new (std::nothrow) mi355rt_scene();
+   if (!s) return fail(MI355RT_E_MEMORY, "out of host memory");
+   s->device = device;
+   for (int c = 0; c < 3; c++) {
+      s->smin[c] = jm::kFloatMax;
+      s->smax[c] = -jm::kFloatMax;
+   }
+   std::vector<DevObject> dev_objs(n_meshes ? n_meshes : 1);
+   std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
+
+   try {
+      for (uint32_t i = 0; i < n_meshes; i++) {
+         const mi355rt_mesh_desc &md = meshes[i];
+         BuiltObject bo_out;
+         const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo, bo_out);
+         if (!err.empty()) {
+            release_scene(s);
+            return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
+         }
+         // leaf slots: 3 x float4 per (leaf, face)
+         std::vector<float> tris(12 * bo_out.slot_face.size());
+         for (size_t sidx = 0; sidx < bo_out.slot_face.size(); sidx++) {
+            const int32_t f = bo_out.slot_face[sidx];
+            float *dst = tris.data() + 12 * sidx;
+            for (int kx = 0; kx < 3; kx++) {
+               const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
+               dst[4 * kx + 0] = v[0];
+               dst[4 * kx + 1] = v[1];
+               dst[4 * kx + 2] = v[2];
+               dst[4 * kx + 3] = 0.0f;
+            }
+            std::memcpy(&dst[3], &f, sizeof(float));
+         }
+         std::vector<float> fnrm(12 * (size_t) md.n_faces);
+         for (size_t f = 0; f < md.n_faces; f++) {
+            float *dst = fnrm.data() + 12 * f;
+            for (int kx = 0; kx < 3; kx++) {
+               const float *nrm = bo_out.normals.data() + 3 * (size_t) md.indices[3 * f + kx];
+               dst[4 * kx + 0] = nrm[0];
+               dst[4 * kx + 1] = nrm[1];
+               dst[4 * kx + 2] = nrm[2];
+               dst[4 * kx + 3] = 0.0f;
+            }
+         }
+         s->objects.emplace_back();
+         s->materials.push_back(md.material);
+         HostObject &ho = s->objects.back();
+         std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
+         std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
+         ho.shadow_distance = bo_out.shadow_distance;
+         ho.n_nodes = bo_out.nodes.size();
+         ho.n_leaves = bo_out.n_leaves;
+         ho.n_slots = bo_out.slot_face.size();
+         ho.max_depth = bo_out.max_depth;
+         int rc;
+         if ((rc = upload(bo_out.nodes.data(), bo_out.nodes.size() * sizeof(NodeRec), &ho.d_nodes, s)) ||
+             (rc = upload(tris.data(), tris.size() * sizeof(float), &ho.d_tris, s)) ||
+             (rc = upload(fnrm.data(), fnrm.size() * sizeof(float), &ho.d_fnrm, s))) {
+            release_scene(s);
+            return rc;
+         }
+         DevObject &d = dev_objs[i];
+         d.nodes = ho.d_nodes;
+         d.tris = ho.d_tris;
+         d.fnrm = ho.d_fnrm;
+         std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
+         std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
+         d.root_link = bo_out.root_link;
+         d.root_cnt = bo_out.root_cnt;
+         d.root_is_leaf = bo_out.root_is_leaf;
+         d.shadow_distance = bo_out.shadow_distance;
+         d.mat.kind = md.material.kind;
+         std::memcpy(d.mat.diffuse, md.material.diffuse, sizeof(d.mat.diffuse));
+         std::memcpy(d.mat.specular, md.material.specular, sizeof(d.mat.specular));
+         d.mat.shininess = md.material.shininess;
+         d.mat.brdf_id = md.material.brdf_id;
+         for (int c = 0; c < 3; c++) {
+            s->smin[c] = jm::fmin_java(s->smin[c], ho.bmin[c]);
+            s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
+         }
+      }
+   } catch (const std::bad_alloc &) {
+      release_scene(s);
+      return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
+   }
+   float amax = 0.f;
+   for (int c = 0; c < 3; c++) {
+      if (std::isfinite(s->smin[c])) amax = std::fmax(amax, std::fabs(s->smin[c]));
+      if (std::isfinite(s->smax[c])) amax = std::fmax(amax, std::fabs(s->smax[c]));
+   }
+   s->abs_max = n_meshes ? amax : 0.f;
+   int rc;
+   if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s))) {
+      release_scene(s);
+      return rc;
+   }
+   hipError_t e = hipMalloc((void **) &s->d_stats, 6 * sizeof(unsigned long long));
+   if (e != hipSuccess) {
+      release_scene(s);
+      return hip_fail(e, "hipMalloc(stats)");
+   }
+   *out = s;
+   return MI355RT_OK;
+}
+
+void mi355rt_scene_destroy(mi355rt_scene *scene)
+{
+   if (!scene) return;
+   DeviceScope scope(scene->device);
+   release_scene(scene);
+}
+
+int mi355rt_brdf_tables(mi355rt_scene *scene, const float *angles, int32_t n_dirs, const float *weights, int32_t n_materials)
+{
+   if (!scene || !angles || !weights) return fail(MI355RT_E_ARG, "null argument");
+   if (n_dirs < 1 || n_materials < 1) return fail(MI355RT_E_ARG, "table sizes must be positive");
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   // BRDFMaterial.remapDirections -> PBRTMath.getRemappedDirection(float[], float[]) PBRTMath.java:74-97
+   const float f_pi = (float) jm::kPi, f_2pi = 2.0f * (float) jm::kPi;
+   std::vector<float> dirs(3 * (size_t) n_dirs);
+   for (int32_t i = 0; i < n_dirs; i++) {
+      const float theta_v = angles[4 * i], phi_v = angles[4 * i + 1], theta_i = angles[4 * i + 2], phi_i = angles[4 * i + 3];
+      const float cosi = (float) std::cos((double) theta_v), coso = (float) std::cos((double) theta_i);
+      const float sini = (float) std::sin((double) theta_v), sino = (float) std::sin((double) theta_i);
+      const float phii = ((double) phi_v < jm::kPi / 2.0f) ? phi_v + 2.0f * f_pi : phi_v;   // PBRTMath.normalizePhi
+      const float phio = ((double) phi_i < jm::kPi / 2.0f) ? phi_i + 2.0f * f_pi : phi_i;
+      float dphi = phii - phio;
+      if (dphi < 0.0f) dphi += f_2pi;
+      if (dphi > f_2pi) dphi -= f_2pi;
+      if (dphi > f_pi) dphi = f_2pi - dphi;
+      dirs[3 * (size_t) i + 0] = sini * sino;
+      dirs[3 * (size_t) i + 1] = dphi / f_pi;
+      dirs[3 * (size_t) i + 2] = cosi * coso;
+   }
+   if (scene->d_brdf_dirs) (void) hipFree(scene->d_brdf_dirs);
+   if (scene->d_brdf_weights) (void) hipFree(scene->d_brdf_weights);
+   scene->d_brdf_dirs = scene->d_brdf_weights = nullptr;
+   scene->n_dirs = scene->n_materials = 0;
+   int rc;
+   if ((rc = upload(dirs.data(), dirs.size() * sizeof(float), (void **) &scene->d_brdf_dirs, scene))) return rc;
+   if ((rc = upload(weights, sizeof(float) * (size_t) n_dirs * (size_t) n_materials, (void **) &scene->d_brdf_weights, scene))) return rc;
+   scene->n_dirs = n_dirs;
+   scene->n_materials = n_materials;
+   return MI355RT_OK;
+}
+
+int mi355rt_scene_epsilon(const mi355rt_scene *scene, float *epsilon_out)
+{
+   if (!scene || !epsilon_out) return fail(MI355RT_E_ARG, "null argument");
+   const float span = jm::fmax_java(scene->smax[0] - scene->smin[0],
+                                    jm::fmax_java(scene->smax[1] - scene->smin[1], scene->smax[2] - scene->smin[2]));
+   *epsilon_out = (span < 10) ? 1e-15f : 1e-3f;   // Scene.java:35-36
+   return MI355RT_OK;
+}
+
+int mi355rt_scene_object_info(const mi355rt_scene *scene, uint32_t object, float minmax[6], float *shadow_distance,
+                              uint64_t *n_nodes, uint64_t *n_leaves, uint64_t *n_leaf_slots, int32_t *max_depth)
+{
+   if (!scene) return fail(MI355RT_E_ARG, "scene is null");
+   if (object >= scene->objects.size()) return fail(MI355RT_E_ARG, "object index out of range");
+   const HostObject &o = scene->objects[object];
+   if (minmax) {
+      std::memcpy(minmax, o.bmin, sizeof(o.bmin));
+      std::memcpy(minmax + 3, o.bmax, sizeof(o.bmax));
+   }
+   if (shadow_distance) *shadow_distance = o.shadow_distance;
+   if (n_nodes) *n_nodes = o.n_nodes;
+   if (n_leaves) *n_leaves = o.n_leaves;
+   if (n_leaf_slots) *n_leaf_slots = o.n_slots;
+   if (max_depth) *max_depth = o.max_depth;
+   return MI355RT_OK;
+}
+
+int mi355rt_scene_device_bytes(const mi355rt_scene *scene, uint64_t *bytes_out)
+{
+   if (!scene || !bytes_out) return fail(MI355RT_E_ARG, "null argument");
+   *bytes_out = scene->device_bytes;
+   return MI355RT_OK;
+}
+
+int mi355rt_camera_setup(const mi355rt_scene *scene, const float orientation_deg[3], float fov_deg, float near_plane, int32_t width,
+                         int32_t height, mi355rt_camera *out)
+{
+   if (!scene || !orientation_deg || !out) return fail(MI355RT_E_ARG, "null argument");
+   if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+   out->near_plane = near_plane;
+   out->width = width;
+   out->height = height;
+   // Camera.java:50-51
+   out->viewport_w = (width >= height ? (float) width / (float) height : 1.0f) * near_plane;
+   out->viewport_h = (width >= height ? 1.0f : (float) height / (float) width) * near_plane;
+   // RTStatics.initializeQuat4f(float[]) RTStatics.java:345-354: yaw(-o0) * pitch(o1) * roll(-o2)
+   const jm::Quat yaw = jm::quat_from_axis_angle({ 0.f, 1.f, 0.f }, -orientation_deg[0]);
+   const jm::Quat pitch = jm::quat_from_axis_angle({ 1.f, 0.f, 0.f }, orientation_deg[1]);
+   const jm::Quat roll = jm::quat_from_axis_angle({ 0.f, 0.f, 1.f }, -orientation_deg[2]);
+   jm::quat_to_rows(jm::quat_mul(jm::quat_mul(yaw, pitch), roll), out->rotation);
+   // Camera.java:72-81
+   const float w = scene->smax[0] - scene->smin[0];
+   const float h = scene->smax[1] - scene->smin[1];
+   const float d = scene->smax[2] - scene->smin[2];
+   const float cx = w / 2.0f + scene->smin[0];
+   const float cy = h / 2.0f + scene->smin[1];
+   const float cz = d / 2.0f + scene->smin[2];
+   const float distance = w / 2.0f / (float) std::tan(jm::to_radians((double) fov_deg));
+   const jm::Vec3 o = jm::rotate(out->rotation, { cx, cy, cz + distance });
+   out->origin[0] = o.x;
+   out->origin[1] = o.y;
+   out->origin[2] = o.z;
+   return MI355RT_OK;
+}
+
+int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_frame *frame,
+                          void *hip_stream)
+{
+   if (!scene || !frame) return fail(MI355RT_E_ARG, "null argument");
+   RenderParams p;
+   if (int rc = fill_render_params(scene, cam, settings, p)) return rc;
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   hipStream_t stream = (hipStream_t) hip_stream;
+   p.rgb = frame->rgb;
+   p.argb8 = frame->argb8;
+   p.hit_id = frame->hit_id;
+   p.hit_obj = frame->hit_obj;
+   p.hit_w = frame->hit_w;
+   const bool stats = settings->collect_stats != 0;
+   if (stats) {
+      HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 6 * sizeof(unsigned long long), stream));
+      p.stats = scene->d_stats;
+      scene->stats_valid = true;
+   }
+   HIP_TRY(launch_render(p, stats, stream));
+   return MI355RT_OK;
+}
+
+int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
+                   int32_t *hit_id_out, float *hit_w_out)
+{
+   if (!scene || !cam) return fail(MI355RT_E_ARG, "null argument");
+   if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   const size_t pixels = (size_t) cam->width * (size_t) cam->height;
+   if (pixels > scene->scratch_pixels) {
+      if (scene->d_rgb) (void) hipFree(scene->d_rgb);
+      if (scene->d_hit_id) (void) hipFree(scene->d_hit_id);
+      if (scene->d_hit_w) (void) hipFree(scene->d_hit_w);
+      scene->d_rgb = nullptr;
+      scene->d_hit_id = nullptr;
+      scene->d_hit_w = nullptr;
+      scene->scratch_pixels = 0;
+      HIP_TRY(hipMalloc((void **) &scene->d_rgb, pixels * 3 * sizeof(float)));
+      HIP_TRY(hipMalloc((void **) &scene->d_hit_id, pixels * sizeof(int32_t)));
+      HIP_TRY(hipMalloc((void **) &scene->d_hit_w, pixels * sizeof(float)));
+      scene->scratch_pixels = pixels;
+   }
+   // tiles owned by other ranks stay zero
+   HIP_TRY(hipMemsetAsync(scene->d_rgb, 0, pixels * 3 * sizeof(float), nullptr));
+   HIP_TRY(hipMemsetAsync(scene->d_hit_id, 0, pixels * sizeof(int32_t), nullptr));
+   HIP_TRY(hipMemsetAsync(scene->d_hit_w, 0, pixels * sizeof(float), nullptr));
+   mi355rt_frame fr;
+   std::memset(&fr, 0, sizeof(fr));
+   fr.rgb = scene->d_rgb;
+   fr.hit_id = scene->d_hit_id;
+   fr.hit_w = scene->d_hit_w;
+   if (int rc = mi355rt_render_device(scene, cam, settings, &fr, nullptr)) return rc;
+   HIP_TRY(hipStreamSynchronize(nullptr));
+   if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, scene->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+   if (hit_id_out) HIP_TRY(hipMemcpy(hit_id_out, scene->d_hit_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+   if (hit_w_out) HIP_TRY(hipMemcpy(hit_w_out, scene->d_hit_w, pixels * sizeof(float), hipMemcpyDeviceToHost));
+   return MI355RT_OK;
+}
+
+int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
+{
+   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+   if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   unsigned long long h[6];
+   HIP_TRY(hipDeviceSynchronize());
+   HIP_TRY(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+   out->primary_rays = h[0];
+   out->shadow_rays = h[1];
+   out->secondary_rays = h[2];
+   out->box_tests = h[3];
+   out->tri_tests = h[4];
+   out->hits = h[5];
+   return MI355RT_OK;
+}
+
+int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, uint64_t n, const float *origins,
+                       const float *directions, int32_t *hit_id, int32_t *hit_obj, float *hit_w, float *hit_point, float *hit_normal)
+{
+   if (!scene || !settings) return fail(MI355RT_E_ARG, "null argument");
+   if (n == 0) return MI355RT_OK;
+   if (!origins || !directions) return fail(MI355RT_E_ARG, "null ray arrays");
+   if (n > ((uint64_t) 1 << 31)) return fail(MI355RT_E_LIMIT, "more than 2^31 rays in one call");
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+
+   struct Buffers {
+      void *p[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+      ~Buffers()
+      {
+         for (void *q : p)
+            if (q) (void) hipFree(q);
+      }
+   } buf;
+   const size_t sizes[7] = { n * 3 * sizeof(float), n * 3 * sizeof(float), n * sizeof(int32_t), n * sizeof(int32_t),
+                             n * sizeof(float),     n * 3 * sizeof(float), n * 3 * sizeof(float) };
+   for (int i = 0; i < 7; i++) HIP_TRY(hipMalloc(&buf.p[i], sizes[i]));
+   HIP_TRY(hipMemcpy(buf.p[0], origins, sizes[0], hipMemcpyHostToDevice));
+   HIP_TRY(hipMemcpy(buf.p[1], directions, sizes[1], hipMemcpyHostToDevice));
+   TraceParams tp;
+   std::memset(&tp, 0, sizeof(tp));
+   tp.epsilon = settings->epsilon;
+   tp.near_plane = settings->near_plane;
+   tp.far_plane = settings->far_plane;
+   tp.n_objs = (int32_t) scene->objects.size();
+   tp.objs = scene->d_objs;
+   tp.scene_abs_max = scene->abs_max;
+   tp.n = n;
+   tp.origins = (const float *) buf.p[0];
+   tp.dirs = (const float *) buf.p[1];
+   tp.hit_id = (int32_t *) buf.p[2];
+   tp.hit_obj = (int32_t *) buf.p[3];
+   tp.hit_w = (float *) buf.p[4];
+   tp.hit_point = (float *) buf.p[5];
+   tp.hit_normal = (float *) buf.p[6];
+   HIP_TRY(launch_trace_rays(tp, nullptr));
+   HIP_TRY(hipStreamSynchronize(nullptr));
+   if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[2], sizes[2], hipMemcpyDeviceToHost));
+   if (hit_obj) HIP_TRY(hipMemcpy(hit_obj, buf.p[3], sizes[3], hipMemcpyDeviceToHost));
+   if (hit_w) HIP_TRY(hipMemcpy(hit_w, buf.p[4], sizes[4], hipMemcpyDeviceToHost));
+   if (hit_point) HIP_TRY(hipMemcpy(hit_point, buf.p[5], sizes[5], hipMemcpyDeviceToHost));
+   if (hit_normal) HIP_TRY(hipMemcpy(hit_normal, buf.p[6], sizes[6], hipMemcpyDeviceToHost));
+   return MI355RT_OK;
+}
+
+int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_div, float *out_sqrt, float *out_rnorm, float *out_pow)
+{
+   if (!a || !b || !out_div || !out_sqrt || !out_rnorm || !out_pow) return fail(MI355RT_E_ARG, "null argument");
+   if (n == 0) return MI355RT_OK;
+   int n_dev = 0;
+   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available");
+   float *d[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+   int rc = MI355RT_OK;
+   for (int i = 0; i < 6 && rc == MI355RT_OK; i++) {
+      hipError_t e = hipMalloc((void **) &d[i], n * sizeof(float));
+      if (e != hipSuccess) rc = hip_fail(e, "hipMalloc");
+   }
+   if (rc == MI355RT_OK) {
+      hipError_t e = hipMemcpy(d[0], a, n * sizeof(float), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMemcpy(d[1], b, n * sizeof(float), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_arith_probe(n, d[0], d[1], d[2], d[3], d[4], d[5], nullptr);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      if (e == hipSuccess) e = hipMemcpy(out_div, d[2], n * sizeof(float), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out_sqrt, d[3], n * sizeof(float), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out_rnorm, d[4], n * sizeof(float), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out_pow, d[5], n * sizeof(float), hipMemcpyDeviceToHost);
+      if (e != hipSuccess) rc = hip_fail(e, "arith probe");
+   }
+   for (float *q : d)
+      if (q) (void) hipFree(q);
+   return rc;
+}
+
+int mi355rt_ply_load(const char *path, uint32_t *n_vertices, uint32_t *n_faces, float **vertices, float **normals, int32_t **indices,
+                     int32_t *has_normals)
+{
+   if (!path || !n_vertices || !n_faces || !vertices || !normals || !indices || !has_normals) return fail(MI355RT_E_ARG, "null argument");
+   PlyMesh m;
+   const std::string err = read_ply(path, m);
+   if (!err.empty()) return fail(MI355RT_E_IO, std::string(path) + ": " + err);
+   float *v = (float *) std::malloc(sizeof(float) * (m.vertices.size() ? m.vertices.size() : 1));
+   float *nr = (float *) std::malloc(sizeof(float) * (m.normals.size() ? m.normals.size() : 1));
+   int32_t *ix = (int32_t *) std::malloc(sizeof(int32_t) * (m.indices.size() ? m.indices.size() : 1));
+   if (!v || !nr || !ix) {
+      std::free(v);
+      std::free(nr);
+      std::free(ix);
+      return fail(MI355RT_E_MEMORY, "out of host memory");
+   }
+   if (!m.vertices.empty()) std::memcpy(v, m.vertices.data(), sizeof(float) * m.vertices.size());
+   if (!m.normals.empty()) std::memcpy(nr, m.normals.data(), sizeof(float) * m.normals.size());
+   if (!m.indices.empty()) std::memcpy(ix, m.indices.data(), sizeof(int32_t) * m.indices.size());
+   *n_vertices = (uint32_t) (m.vertices.size() / 3);
+   *n_faces = (uint32_t) (m.indices.size() / 3);
+   *vertices = v;
+   *normals = nr;
+   *indices = ix;
+   *has_normals = m.has_normals ? 1 : 0;
+   return MI355RT_OK;
+}
+
+int mi355rt_compute_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, float *normals_out)
+{
+   if ((n_vertices && !vertices) || (n_faces && !indices) || !normals_out) return fail(MI355RT_E_ARG, "null argument");
+   for (size_t i = 0; i < 3 * (size_t) n_faces; i++) {
+      if (indices[i] < 0 || (uint32_t) indices[i] >= n_vertices) return fail(MI355RT_E_ARG, "face index out of range");
+   }
+   synthesise_normals(vertices, n_vertices, indices, n_faces, normals_out);
+   return MI355RT_OK;
+}
+
+void mi355rt_free(void *p) { std::free(p); }
+
+}   // extern "C"

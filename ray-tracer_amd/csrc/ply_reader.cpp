@@ -1,0 +1,200 @@
+// ply_reader.cpp -- whole-file, cursor-based PLY parse that yields what the reference loader yields
+// (sceneObjects/TriangleMesh.java).  Behaviours kept on purpose:
+//   * header: "element vertex N", "element face N"; a property's slot is its rank among ALL non-list
+//     property lines; slots are recognised by line suffix, " nx"/" ny"/" nz" first, then " x"/" y"/" z"
+//     (TriangleMesh.java:41-70);
+//   * ASCII body: fields separated by exactly one space (String.split(" ")), faces use fields 1..3
+//     and run to end of file (:128-153);
+//   * binary body: big-endian only (DataInputStream), every vertex property a 4-byte float, one
+//     list-count byte skipped per face, three 4-byte indices (:155-197).
+// Where the reference would die with an exception (short file, unparsable field) this returns an
+// error string instead of exiting the process (TriangleMesh.java:90-93).
+#include "ply_reader.hpp"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace mi355rt {
+
+namespace {
+
+struct Cursor {
+   const char *p, *end;
+   // one text line as BufferedReader.readLine sees it; false at end of data
+   bool line(const char *&b, const char *&e)
+   {
+      if (p >= end) return false;
+      b = p;
+      while (p < end && *p != '\n' && *p != '\r') ++p;
+      e = p;
+      if (p < end) {
+         if (*p == '\r' && p + 1 < end && p[1] == '\n') p += 2;
+         else ++p;
+      }
+      return true;
+   }
+};
+
+bool has_prefix(const char *b, const char *e, const char *lit)
+{
+   const size_t n = std::strlen(lit);
+   return (size_t) (e - b) >= n && std::memcmp(b, lit, n) == 0;
+}
+bool has_suffix(const char *b, const char *e, const char *lit)
+{
+   const size_t n = std::strlen(lit);
+   return (size_t) (e - b) >= n && std::memcmp(e - n, lit, n) == 0;
+}
+
+// fields of a line split on single spaces, trailing empty fields dropped
+void fields(const char *b, const char *e, std::vector<std::string> &out)
+{
+   out.clear();
+   const char *s = b;
+   for (const char *q = b;; ++q) {
+      if (q == e || *q == ' ') {
+         out.emplace_back(s, q);
+         if (q == e) break;
+         s = q + 1;
+      }
+   }
+   while (!out.empty() && out.back().empty()) out.pop_back();
+}
+
+bool to_float(const std::string &s, float &v)
+{
+   if (s.empty()) return false;
+   char *endp = nullptr;
+   v = std::strtof(s.c_str(), &endp);
+   return endp && *endp == 0;
+}
+bool to_int(const std::string &s, int32_t &v)
+{
+   if (s.empty() || s[0] == ' ' || s[0] == '\t') return false;
+   char *endp = nullptr;
+   errno = 0;
+   const long x = std::strtol(s.c_str(), &endp, 10);
+   if (!endp || *endp != 0 || errno || x < INT32_MIN || x > INT32_MAX) return false;
+   v = (int32_t) x;
+   return true;
+}
+
+uint32_t be32(const unsigned char *q) { return ((uint32_t) q[0] << 24) | ((uint32_t) q[1] << 16) | ((uint32_t) q[2] << 8) | (uint32_t) q[3]; }
+
+}   // namespace
+
+std::string read_ply(const char *path, PlyMesh &out)
+{
+   std::FILE *f = std::fopen(path, "rb");
+   if (!f) return "cannot open file";
+   std::string data;
+   {
+      char chunk[1 << 16];
+      size_t got;
+      while ((got = std::fread(chunk, 1, sizeof(chunk), f)) > 0) data.append(chunk, got);
+   }
+   std::fclose(f);
+
+   Cursor cur { data.data(), data.data() + data.size() };
+   const char *b, *e;
+   int32_t n_vertices = 0, n_faces = 0;
+   int slot = 0, sx = -1, sy = -1, sz = -1, snx = -1, sny = -1, snz = -1;
+   bool ascii = true, in_body = false;
+   std::vector<std::string> fl;
+
+   while (!in_body && cur.line(b, e)) {
+      if (has_prefix(b, e, "element vertex")) {
+         fields(b, e, fl);
+         if (fl.size() < 3 || !to_int(fl[2], n_vertices) || n_vertices < 0) return "bad 'element vertex' line";
+      } else if (has_prefix(b, e, "element face")) {
+         fields(b, e, fl);
+         if (fl.size() < 3 || !to_int(fl[2], n_faces) || n_faces < 0) return "bad 'element face' line";
+      } else if (has_prefix(b, e, "property")) {
+         if (has_suffix(b, e, " nx")) snx = slot;
+         else if (has_suffix(b, e, " ny")) sny = slot;
+         else if (has_suffix(b, e, " nz")) snz = slot;
+         else if (has_suffix(b, e, " x")) sx = slot;
+         else if (has_suffix(b, e, " y")) sy = slot;
+         else if (has_suffix(b, e, " z")) sz = slot;
+         if (!has_prefix(b, e, "property list")) slot++;
+      } else if (has_prefix(b, e, "format binary")) {
+         ascii = false;
+      } else if ((size_t) (e - b) == 10 && std::memcmp(b, "end_header", 10) == 0) {
+         in_body = true;
+      }
+   }
+   if (sx < 0 || sy < 0 || sz < 0) return "header declares no x/y/z vertex properties";
+   const bool has_n = snx >= 0 && sny >= 0 && snz >= 0;
+
+   out = PlyMesh();
+   out.has_normals = has_n;
+   out.vertices.assign(3 * (size_t) n_vertices, 0.0f);
+   out.normals.assign(3 * (size_t) n_vertices, 0.0f);
+   out.indices.assign(3 * (size_t) n_faces, 0);
+
+   if (ascii) {
+      for (int32_t i = 0; i < n_vertices; i++) {
+         if (!cur.line(b, e)) return "file ends inside the vertex list";
+         fields(b, e, fl);
+         const int need = has_n ? std::max(std::max(sx, sy), std::max(std::max(sz, snx), std::max(sny, snz))) : std::max(sx, std::max(sy, sz));
+         if ((int) fl.size() <= need) return "vertex line " + std::to_string(i) + " has too few fields";
+         float *v = &out.vertices[3 * (size_t) i];
+         if (!to_float(fl[(size_t) sx], v[0]) || !to_float(fl[(size_t) sy], v[1]) || !to_float(fl[(size_t) sz], v[2]))
+            return "unparsable coordinate on vertex line " + std::to_string(i);
+         if (has_n) {
+            float *n = &out.normals[3 * (size_t) i];
+            if (!to_float(fl[(size_t) snx], n[0]) || !to_float(fl[(size_t) sny], n[1]) || !to_float(fl[(size_t) snz], n[2]))
+               return "unparsable normal on vertex line " + std::to_string(i);
+         }
+      }
+      int32_t row = 0;
+      while (cur.line(b, e)) {
+         fields(b, e, fl);
+         if (row >= n_faces) return "more face lines than 'element face' declares";
+         if (fl.size() < 4) return "face line " + std::to_string(row) + " has fewer than 4 fields";
+         int32_t *t = &out.indices[3 * (size_t) row];
+         if (!to_int(fl[1], t[0]) || !to_int(fl[2], t[1]) || !to_int(fl[3], t[2])) return "unparsable index on face line " + std::to_string(row);
+         row++;
+      }
+      return std::string();
+   }
+
+   // binary: the reference re-opens the file and skips '\n'-terminated lines up to the one that
+   // starts with "end_header"
+   const char *q = data.data(), *qe = data.data() + data.size();
+   for (;;) {
+      const char *nl = (const char *) std::memchr(q, '\n', (size_t) (qe - q));
+      if (!nl) return "binary file has no end_header line";
+      const bool last = has_prefix(q, nl, "end_header");
+      q = nl + 1;
+      if (last) break;
+   }
+   const size_t vbytes = (size_t) n_vertices * (size_t) slot * 4;
+   const size_t fbytes = (size_t) n_faces * 13;
+   if ((size_t) (qe - q) < vbytes) return "file ends inside the vertex block";
+   const unsigned char *u = (const unsigned char *) q;
+   for (int32_t i = 0; i < n_vertices; i++, u += (size_t) slot * 4) {
+      const int src[3] = { sx, sy, sz };
+      for (int c = 0; c < 3; c++) {
+         const uint32_t bits = be32(u + 4 * (size_t) src[c]);
+         std::memcpy(&out.vertices[3 * (size_t) i + c], &bits, 4);
+      }
+      if (has_n) {
+         const int nsrc[3] = { snx, sny, snz };
+         for (int c = 0; c < 3; c++) {
+            const uint32_t bits = be32(u + 4 * (size_t) nsrc[c]);
+            std::memcpy(&out.normals[3 * (size_t) i + c], &bits, 4);
+         }
+      }
+   }
+   if ((size_t) ((const unsigned char *) qe - u) < fbytes) return "file ends inside the face block";
+   for (int32_t i = 0; i < n_faces; i++, u += 13) {
+      for (int c = 0; c < 3; c++) out.indices[3 * (size_t) i + c] = (int32_t) be32(u + 1 + 4 * c);
+   }
+   return std::string();
+}
+
+}   // namespace mi355rt

@@ -1,0 +1,368 @@
+"""Host-side mirror of the reference's renderer interface, over the C ABI of libmi355rt.so.
+
+The reference is Java and no JDK exists in this pipeline, so this mirror (same class names,
+argument order and meaning as the Java classes it stands in for) is what the parity tests and the
+benchmark drive.  It holds no arithmetic of the hot path: scene build, camera constants, tracing
+and shading all happen behind include/mi355rt.h.
+
+    reference (src/stephen/ranger/ar/...)              here
+    RTStatics (settings)              RTStatics.java:18-37      RTStatics
+    lighting/Light                    Light.java:7-16           Light
+    lighting/LightingModel            LightingModel.java        LightingModel
+    lighting/PhongLightingModel       PhongLightingModel.java   PhongLightingModel
+    materials/ColorInformation        ColorInformation.java     ColorInformation
+    materials/BRDFMaterial            BRDFMaterial.java         BRDFMaterial
+    materials/ReflectionMaterial      ReflectionMaterial.java   ReflectionMaterial
+    sceneObjects/TriangleMesh         TriangleMesh.java         TriangleMesh
+    Scene                             Scene.java                Scene
+    Camera                            Camera.java               Camera
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+
+class RTStatics:
+    """RTStatics.java:18-25 -- mutable global settings, as in the reference."""
+    EPSILON = 1e-15
+    NEAR_PLANE = 0.01
+    FAR_PLANE = 3000.0
+    MAX_RECURSION_DEPTH = 5
+    MAX_CHILDREN = 5
+    MAX_DEPTH = 20
+    # not in the reference: cap on mirror-to-mirror recursion, where KDTree.getColor has no cut-off
+    MAX_MIRROR_BOUNCES = 64
+
+
+def _f32(a, shape=None):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    if shape is not None:
+        arr = arr.reshape(shape)
+    return arr
+
+
+def _fp(arr):
+    return arr.ctypes.data_as(_abi.c_float_p)
+
+
+def _ip(arr):
+    return arr.ctypes.data_as(_abi.c_int32_p)
+
+
+class Light:
+    """Light(origin, emission, ambient) -- colours as float RGB triples (Color.getColorComponents)."""
+
+    def __init__(self, origin=(100.0, 100.0, 100.0), emission=(1.0, 1.0, 1.0), ambient=(1.0, 1.0, 1.0)):
+        self.origin = tuple(float(v) for v in origin)
+        self.emission = tuple(float(v) for v in emission)
+        self.ambient = tuple(float(v) for v in ambient)
+
+
+class LightingModel:
+    """LightingModel: pixel colour = material colour."""
+    kind = _abi.LIGHTING_PLAIN
+
+    def __init__(self):
+        self.camera = None
+
+    def setCamera(self, camera):
+        self.camera = camera
+
+
+class PhongLightingModel(LightingModel):
+    """PhongLightingModel(light, objects): one point light, one shadow ray."""
+    kind = _abi.LIGHTING_PHONG
+
+    def __init__(self, light, objects=None):
+        super().__init__()
+        self.light = light
+        self.objects = objects
+
+
+class ColorInformation:
+    """ColorInformation(diffuse[, shininess]) or (emission, ambient, diffuse, specular, shininess)."""
+    kind = _abi.MAT_COLOR
+    brdf_id = 0
+
+    def __init__(self, *args):
+        black = (0.0, 0.0, 0.0)
+        if len(args) == 0:
+            args = (black,)
+        if len(args) == 1:
+            args = (args[0], 20.0)
+        if len(args) == 2:
+            diffuse, shininess = args
+            args = (black, diffuse, diffuse, diffuse, shininess)
+        if len(args) != 5:
+            raise TypeError("ColorInformation takes 0, 1, 2 or 5 arguments")
+        self.emission, self.ambient, self.diffuse, self.specular = (tuple(float(v) for v in c) for c in args[:4])
+        self.shininess = float(args[4])
+
+    def _abi_material(self):
+        m = _abi.Material()
+        m.kind = self.kind
+        m.emission[:] = self.emission
+        m.ambient[:] = self.ambient
+        m.diffuse[:] = self.diffuse
+        m.specular[:] = self.specular
+        m.shininess = self.shininess
+        m.brdf_id = int(self.brdf_id)
+        return m
+
+
+class BRDFMaterial(ColorInformation):
+    """BRDFMaterial(materialID, color).  The parsed CUReT tables are handed over once through
+    BRDFMaterial.setTables(angles[n,4], weights[m,n]) (the Java statics brdfDirections / brdfWeights)."""
+    kind = _abi.MAT_BRDF
+    tables = None
+
+    def __init__(self, materialID, color):
+        super().__init__(color)
+        self.brdf_id = int(materialID)
+
+    @classmethod
+    def setTables(cls, angles, weights):
+        angles = _f32(angles)
+        weights = _f32(weights)
+        if angles.ndim != 2 or angles.shape[1] != 4 or weights.ndim != 2 or weights.shape[1] != angles.shape[0]:
+            raise ValueError("need angles[n,4] and weights[m,n]")
+        cls.tables = (angles, weights)
+
+    @staticmethod
+    def parseBRDFFile(path):
+        """The token rule of BRDFMaterial.parseBRDFFile (BRDFMaterial.java:109-116): split each line on
+        single spaces, drop token 0, keep tokens that contain a digit."""
+        rows = []
+        with open(path, "r") as f:
+            for line in f.read().splitlines():
+                toks = line.split(" ")
+                while toks and toks[-1] == "":
+                    toks.pop()
+                rows.append([np.float32(t) for t in toks[1:] if any(ch.isdigit() for ch in t)])
+        return rows
+
+
+class ReflectionMaterial(ColorInformation):
+    """ReflectionMaterial(diffuse): ColorInformation(diffuse, 100) whose colour is a mirror bounce."""
+    kind = _abi.MAT_REFLECTION
+
+    def __init__(self, diffuse):
+        super().__init__(diffuse, 100.0)
+
+
+class TriangleMesh:
+    """TriangleMesh(modelLocation, colorInfo, computeKDTree).
+
+    modelLocation is a PLY path (parsed by the library's reader with the reference loader's rules) or
+    a (vertices[n,3], indices[f,3]) / (vertices, indices, normals) tuple of arrays."""
+
+    def __init__(self, modelLocation, colorInfo, computeKDTree=True):
+        self.colorInfo = colorInfo
+        self.computeKDTree = bool(computeKDTree)
+        if isinstance(modelLocation, (str, bytes)):
+            self.vertices, self.indices, self.normals = load_ply(modelLocation)
+        else:
+            verts, idx = modelLocation[0], modelLocation[1]
+            nrm = modelLocation[2] if len(modelLocation) > 2 else None
+            self.vertices = _f32(verts).reshape(-1, 3)
+            self.indices = np.ascontiguousarray(np.asarray(idx, dtype=np.int32)).reshape(-1, 3)
+            self.normals = None if nrm is None else _f32(nrm).reshape(-1, 3)
+
+    def getBoundingVolume(self):
+        return self
+
+
+def load_ply(path):
+    """mi355rt_ply_load: returns (vertices, indices, normals-or-None)."""
+    lib = _abi.load()
+    nv, nf, hn = C.c_uint32(), C.c_uint32(), C.c_int32()
+    pv, pn, pi = _abi.c_float_p(), _abi.c_float_p(), _abi.c_int32_p()
+    if isinstance(path, str):
+        path = path.encode()
+    _abi.check(lib.mi355rt_ply_load(path, C.byref(nv), C.byref(nf), C.byref(pv), C.byref(pn), C.byref(pi), C.byref(hn)))
+    try:
+        v = np.ctypeslib.as_array(pv, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy().reshape(-1, 3)
+        n = np.ctypeslib.as_array(pn, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy().reshape(-1, 3)
+        i = np.ctypeslib.as_array(pi, shape=(max(nf.value, 1) * 3,))[: nf.value * 3].copy().reshape(-1, 3)
+    finally:
+        lib.mi355rt_free(pv)
+        lib.mi355rt_free(pn)
+        lib.mi355rt_free(pi)
+    return v, i, (n if hn.value else None)
+
+
+def compute_normals(vertices, indices):
+    """mi355rt_compute_normals (TriangleMesh.computeNormals)."""
+    lib = _abi.load()
+    v = _f32(vertices).reshape(-1, 3)
+    i = np.ascontiguousarray(np.asarray(indices, dtype=np.int32)).reshape(-1, 3)
+    out = np.empty_like(v)
+    _abi.check(lib.mi355rt_compute_normals(_fp(v), v.shape[0], _ip(i), i.shape[0], _fp(out)))
+    return out
+
+
+class Scene:
+    """Scene(objects, light, cameraOrientation, lightingModel, fov).
+
+    Like the reference's constructor it sets the global RTStatics.EPSILON from the scene's span
+    (Scene.java:35-36); unlike it, it also hands the meshes to the library, which builds the
+    reference's hierarchy and uploads it to the GPU (`device`: HIP ordinal, -1 = current)."""
+
+    def __init__(self, objects, light, cameraOrientation, lightingModel, fov, device=-1):
+        self.objects = [o.getBoundingVolume() for o in objects]
+        self.light = light
+        self.cameraOrientation = tuple(float(v) for v in cameraOrientation)
+        self.lightingModel = lightingModel
+        self.fov = float(fov)
+        self._lib = _abi.load()
+        self._handle = C.c_void_p()
+
+        descs = (_abi.MeshDesc * max(len(self.objects), 1))()
+        keep = []
+        use_kd = True
+        for k, mesh in enumerate(self.objects):
+            v, i, n = mesh.vertices, mesh.indices, mesh.normals
+            keep += [v, i, n]
+            descs[k].vertices = _fp(v)
+            descs[k].normals = _fp(n) if n is not None else None
+            descs[k].indices = _ip(i)
+            descs[k].n_vertices = v.shape[0]
+            descs[k].n_faces = i.shape[0]
+            descs[k].material = mesh.colorInfo._abi_material()
+            use_kd = use_kd and mesh.computeKDTree
+        opts = _abi.BuildOpts(RTStatics.MAX_DEPTH, RTStatics.MAX_CHILDREN, 1 if use_kd else 0, int(device))
+        _abi.check(self._lib.mi355rt_scene_create(descs, len(self.objects), C.byref(opts), C.byref(self._handle)))
+        if any(isinstance(m.colorInfo, BRDFMaterial) for m in self.objects):
+            if BRDFMaterial.tables is None:
+                raise ValueError("BRDFMaterial.setTables(angles, weights) must be called before building a BRDF scene")
+            ang, wts = BRDFMaterial.tables
+            _abi.check(self._lib.mi355rt_brdf_tables(self._handle, _fp(ang), ang.shape[0], _fp(wts), wts.shape[0]))
+        eps = C.c_float()
+        _abi.check(self._lib.mi355rt_scene_epsilon(self._handle, C.byref(eps)))
+        RTStatics.EPSILON = float(eps.value)
+
+    def object_info(self, k):
+        mm = (C.c_float * 6)()
+        sd = C.c_float()
+        nn, nl, ns = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        md = C.c_int32()
+        _abi.check(self._lib.mi355rt_scene_object_info(self._handle, k, mm, C.byref(sd), C.byref(nn), C.byref(nl),
+                                                       C.byref(ns), C.byref(md)))
+        return {"minmax": np.array(mm[:], dtype=np.float32), "shadow_distance": np.float32(sd.value),
+                "n_nodes": nn.value, "n_leaves": nl.value, "n_leaf_slots": ns.value, "max_depth": md.value}
+
+    def device_bytes(self):
+        b = C.c_uint64()
+        _abi.check(self._lib.mi355rt_scene_device_bytes(self._handle, C.byref(b)))
+        return b.value
+
+    def close(self):
+        if getattr(self, "_handle", None) and self._handle.value:
+            self._lib.mi355rt_scene_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Camera:
+    """Camera(scene, multiSamples, brdfSamples, nearPlane, screenWidth, screenHeight).
+
+    createImage() is the drop-in seam (Camera.java:119): here it blocks until the frame is done and
+    fills `pixels` (float32 [W][H][3], as Camera.pixels[x][y]), `hit_id` and `hit_w` ([W][H])."""
+
+    def __init__(self, scene, multiSamples, brdfSamples, nearPlane, screenWidth, screenHeight, rng_seed=0):
+        self.scene = scene
+        self.objects = scene.objects
+        self.lightingModel = scene.lightingModel
+        self.light = scene.light
+        self.multiSamples = int(multiSamples)
+        self.brdfSamples = int(brdfSamples)
+        self.orientation = scene.cameraOrientation
+        self.nearPlaneDistance = float(nearPlane)
+        self.screenWidth = int(screenWidth)
+        self.screenHeight = int(screenHeight)
+        self.rng_seed = int(rng_seed)
+        self.listeners = []
+        self._lib = _abi.load()
+        self._cam = _abi.CameraDesc()
+        orient = (C.c_float * 3)(*self.orientation)
+        _abi.check(self._lib.mi355rt_camera_setup(scene._handle, orient, scene.fov, self.nearPlaneDistance,
+                                                  self.screenWidth, self.screenHeight, C.byref(self._cam)))
+        self.origin = np.array(self._cam.origin[:], dtype=np.float32)
+        self.rotation = np.array(self._cam.rotation[:], dtype=np.float32).reshape(3, 3)
+        self.viewportWidth = float(self._cam.viewport_w)
+        self.viewportHeight = float(self._cam.viewport_h)
+        self.pixels = None
+        self.hit_id = None
+        self.hit_w = None
+        self.lightingModel.setCamera(self)
+
+    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False):
+        st = _abi.Settings()
+        st.epsilon = RTStatics.EPSILON
+        st.near_plane = RTStatics.NEAR_PLANE
+        st.far_plane = RTStatics.FAR_PLANE
+        st.max_recursion_depth = RTStatics.MAX_RECURSION_DEPTH
+        st.multi_samples = self.multiSamples
+        st.brdf_samples = self.brdfSamples
+        st.lighting_model = self.lightingModel.kind
+        st.max_mirror_bounces = RTStatics.MAX_MIRROR_BOUNCES
+        st.rng_seed = self.rng_seed
+        st.light_origin[:] = self.light.origin
+        st.light_emission[:] = self.light.emission
+        st.light_ambient[:] = self.light.ambient
+        st.tile_size = tile_size
+        st.tile_rank = tile_rank
+        st.tile_world = tile_world
+        st.collect_stats = 1 if collect_stats else 0
+        return st
+
+    def addActionListener(self, listener):
+        self.listeners.append(listener)
+
+    def createImage(self):
+        W, H = self.screenWidth, self.screenHeight
+        rgb = np.empty((H, W, 3), dtype=np.float32)
+        hid = np.empty((H, W), dtype=np.int32)
+        hw = np.empty((H, W), dtype=np.float32)
+        st = self.settings()
+        _abi.check(self._lib.mi355rt_render(self.scene._handle, C.byref(self._cam), C.byref(st), _fp(rgb), _ip(hid), _fp(hw)))
+        self._rgb_rows = rgb
+        self.pixels = rgb.transpose(1, 0, 2)   # [x][y][c] like Camera.pixels
+        self.hit_id = hid.T
+        self.hit_w = hw.T
+        for listener in self.listeners:   # ActionEvent id 1, "finished" (Camera.java:170-172)
+            listener(self, 1, "finished")
+        self.listeners = []
+
+    def render_device(self, frame, stream=None, **kw):
+        """mi355rt_render_device: `frame` is an _abi.Frame of device pointers; asynchronous."""
+        st = self.settings(**kw)
+        _abi.check(self._lib.mi355rt_render_device(self.scene._handle, C.byref(self._cam), C.byref(st), C.byref(frame),
+                                                   C.c_void_p(stream) if stream else None))
+
+    def frame_stats(self):
+        s = _abi.Stats()
+        _abi.check(self._lib.mi355rt_frame_stats(self.scene._handle, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _abi.Stats._fields_}
+
+    def getClosestIntersection(self, origins, directions):
+        """Camera.getClosestIntersection(null, origin, direction, null, 0) for arrays of rays."""
+        o = _f32(origins).reshape(-1, 3)
+        d = _f32(directions).reshape(-1, 3)
+        n = o.shape[0]
+        hid = np.empty(n, dtype=np.int32)
+        hobj = np.empty(n, dtype=np.int32)
+        hw = np.empty(n, dtype=np.float32)
+        hp = np.empty((n, 3), dtype=np.float32)
+        hn = np.empty((n, 3), dtype=np.float32)
+        st = self.settings()
+        _abi.check(self._lib.mi355rt_trace_rays(self.scene._handle, C.byref(st), n, _fp(o), _fp(d), _ip(hid), _ip(hobj),
+                                                _fp(hw), _fp(hp), _fp(hn)))
+        return {"face": hid, "object": hobj, "w": hw, "point": hp, "normal": hn}

@@ -1,0 +1,69 @@
+"""Shared scene set-up for the parity tests: the same meshes, camera and settings go to the HIP path
+(through the C ABI) and to the oracle."""
+import numpy as np
+
+import oracle
+import ray_tracer_amd as rt
+
+LIGHT = dict(origin=(0.0, 100.0, 100.0), emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))   # RayTracer.java:106
+
+
+def to_orc_material(ci):
+    return oracle.material(kind=ci.kind, diffuse=ci.diffuse, shininess=ci.shininess, brdf_id=ci.brdf_id,
+                           specular=ci.specular, ambient=ci.ambient, emission=ci.emission)
+
+
+class Pair:
+    """One scene built on both sides."""
+
+    def __init__(self, meshes, orientation=(0, 0, 0), fov=15.0, phong=True, light=None, brdf_tables=None,
+                 use_kdtree=True):
+        # meshes: list of (vertices, indices, normals-or-None, ColorInformation)
+        light = light or LIGHT
+        self.light = rt.Light(light["origin"], light["emission"], light["ambient"])
+        if brdf_tables is not None:
+            rt.BRDFMaterial.setTables(*brdf_tables)
+        tms = [rt.TriangleMesh((v, i) if n is None else (v, i, n), ci, use_kdtree) for (v, i, n, ci) in meshes]
+        lm = rt.PhongLightingModel(self.light, tms) if phong else rt.LightingModel()
+        self.scene = rt.Scene(tms, self.light, orientation, lm, fov)
+        self.oscene = oracle.OracleScene([(v, i, n, to_orc_material(ci)) for (v, i, n, ci) in meshes],
+                                         max_depth=rt.RTStatics.MAX_DEPTH, max_children=rt.RTStatics.MAX_CHILDREN,
+                                         use_kdtree=use_kdtree)
+        if brdf_tables is not None:
+            self.oscene.set_brdf(*brdf_tables)
+        self.phong = phong
+        self.orientation = orientation
+        self.fov = fov
+        self.eps = self.oscene.epsilon()
+        assert np.float32(self.eps) == np.float32(rt.RTStatics.EPSILON)
+
+    def cameras(self, W, H, ms=1, brdf_samples=1, seed=0):
+        cam = rt.Camera(self.scene, ms, brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=seed)
+        ocam = self.oscene.camera(self.orientation, self.fov, rt.RTStatics.NEAR_PLANE, W, H)
+        ost = oracle.settings(epsilon=self.eps, ms=ms, brdf_samples=brdf_samples, lighting=1 if self.phong else 0, seed=seed,
+                              light_origin=self.light.origin, light_emission=self.light.emission,
+                              light_ambient=self.light.ambient, bounces=rt.RTStatics.MAX_MIRROR_BOUNCES)
+        return cam, ocam, ost
+
+    def close(self):
+        self.scene.close()
+        self.oscene.close()
+
+
+def synthetic_brdf_tables(n_dirs=205, n_materials=8, seed=7):
+    """Tables shaped like the CUReT ones (table.txt: theta_v phi_v theta_i phi_i; abrdf.dat rows)."""
+    rs = np.random.RandomState(seed)
+    ang = np.stack([rs.uniform(0.0, 1.45, n_dirs), rs.uniform(-np.pi, np.pi, n_dirs),
+                    rs.uniform(0.0, 1.45, n_dirs), rs.uniform(-np.pi, np.pi, n_dirs)], axis=1).astype(np.float32)
+    ang[1, 1] = 0.0   # a phi = 0 row, like row 2 of the real table
+    w = rs.uniform(0.02, 0.35, size=(n_materials, n_dirs)).astype(np.float32)
+    return ang, w
+
+
+def compare_frames(g_rgb, g_id, g_w, o, rtol=1e-3, atol=1e-6):
+    """ids and w bit-exact; radiance within 1e-3 relative (north_star), NaN-scrubbed pixels equal."""
+    ids_equal = np.array_equal(g_id, o["hit_id"])
+    w_equal = np.array_equal(g_w.view(np.uint32), o["hit_w"].view(np.uint32))
+    denom = np.maximum(np.abs(o["rgb"]), atol / rtol)
+    rel = np.abs(g_rgb - o["rgb"]) / denom
+    return ids_equal, w_equal, float(rel.max()), int((g_id != o["hit_id"]).sum())

@@ -1,0 +1,148 @@
+"""HIP path vs oracle, through the C ABI, on the same seeded inputs (bit-exact ids and w; radiance
+within the north star's 1e-3 relative)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob_pair(rt, faces, name="bunny", **kw):
+    from helpers import Pair
+    cfg = rt.meshgen.STANFORD[name]
+    v, i = rt.meshgen.stanford_standin(name, faces)
+    ci = kw.pop("colorInfo", None) or rt.ColorInformation((1.0, 1.0, 1.0))
+    return Pair([(v, i, None, ci)], orientation=cfg["orientation"], fov=cfg["fov"], **kw)
+
+
+def _check(pair, W, H, ms=1, brdf_samples=1, seed=0, rtol=1e-3):
+    from helpers import compare_frames
+    cam, ocam, ost = pair.cameras(W, H, ms=ms, brdf_samples=brdf_samples, seed=seed)
+    np.testing.assert_array_equal(np.array(ocam.origin[:], dtype=np.float32), cam.origin)
+    np.testing.assert_array_equal(np.array(ocam.rotation[:], dtype=np.float32).reshape(3, 3), cam.rotation)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=8)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, rtol=rtol)
+    assert ids_equal, "%d pixels differ in hit id" % n_diff
+    assert w_equal
+    assert max_rel <= rtol, max_rel
+    hit_frac = float((o["hit_id"] >= 0).mean())
+    return hit_frac
+
+
+def test_device_arithmetic_is_correctly_rounded(rt):
+    """f32 divide / sqrt and the f64 normalise scale must equal IEEE (= Java) results bit for bit."""
+    import ctypes as C
+    rs = np.random.RandomState(3)
+    n = 1 << 18
+    a = np.abs(rs.standard_normal(n).astype(np.float32)) * np.float32(10.0) ** rs.randint(-20, 20, n).astype(np.float32)
+    a[:4] = [1e-40, 3e-39, 1.0, 2.0]   # subnormals too
+    b = rs.standard_normal(n).astype(np.float32)
+    b[b == 0] = 1
+    outs = [np.empty(n, dtype=np.float32) for _ in range(4)]
+    lib = rt._abi.load()
+    P = lambda x: x.ctypes.data_as(rt._abi.c_float_p)
+    rt._abi.check(lib.mi355rt_debug_arith(n, P(a), P(b), *[P(x) for x in outs]))
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(outs[0].view(np.uint32), (a / b).view(np.uint32))
+        np.testing.assert_array_equal(outs[1].view(np.uint32), np.sqrt(a).view(np.uint32))
+        ref = (1.0 / np.sqrt(a.astype(np.float64))).astype(np.float32)
+        np.testing.assert_array_equal(outs[2].view(np.uint32), ref.view(np.uint32))
+        refp = np.power(b.astype(np.float64), 20.0).astype(np.float32)
+        ok = np.isclose(outs[3], refp, rtol=1e-6, atol=0) | (outs[3] == refp)
+        assert ok.all()
+
+
+def test_bunny_small_phong(rt):
+    pair = _blob_pair(rt, 5000)
+    frac = _check(pair, 96, 96)
+    assert 0.05 < frac < 0.95
+    pair.close()
+
+
+def test_bunny_config1_phong(rt):
+    """BASELINE config 1: ~69k faces, 512x512, 1 spp, primary + shadow."""
+    pair = _blob_pair(rt, None)
+    _check(pair, 512, 512)
+    pair.close()
+
+
+def test_multisample_jitter(rt):
+    pair = _blob_pair(rt, 20000)
+    _check(pair, 160, 90, ms=4, seed=1234)
+    pair.close()
+
+
+def test_plain_lighting_model(rt):
+    pair = _blob_pair(rt, 3000, phong=False)
+    _check(pair, 64, 64)
+    pair.close()
+
+
+def test_no_kdtree(rt):
+    pair = _blob_pair(rt, 600, use_kdtree=False)
+    _check(pair, 48, 48)
+    pair.close()
+
+
+def test_brdf_material(rt):
+    from helpers import synthetic_brdf_tables
+    pair = _blob_pair(rt, 8000, name="buddha", colorInfo=rt.BRDFMaterial(3, (0.2, 0.8, 0.3)),
+                      brdf_tables=synthetic_brdf_tables())
+    _check(pair, 96, 128, brdf_samples=2)
+    pair.close()
+
+
+def test_reflection_two_objects(rt):
+    from helpers import Pair
+    v, i = rt.meshgen.blob(6000, span=0.2, seed=11)
+    fv, fi = rt.meshgen.quad(-0.12, 0.6)
+    pair = Pair([(v, i, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))), (fv, fi, None, rt.ColorInformation((0.8, 0.3, 0.2)))],
+                orientation=(0, 20, 0), fov=20.0)
+    _check(pair, 128, 96, ms=2, seed=5)
+    pair.close()
+
+
+def test_large_scale_epsilon_branch(rt):
+    """span >= 10 selects EPSILON = 1e-3 (Scene.java:36)."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(4000, span=400.0, seed=4)
+    pair = Pair([(v, i, None, rt.ColorInformation((1, 1, 1)))], fov=10.0)
+    assert np.float32(pair.eps) == np.float32(1e-3)
+    _check(pair, 80, 80)
+    pair.close()
+
+
+def test_triangle_soup(rt):
+    from helpers import Pair
+    v, i = rt.meshgen.soup(20000, span=0.3, tri_size=0.03, seed=9)
+    pair = Pair([(v, i, None, rt.ColorInformation((0.9, 0.9, 0.9)))], fov=23.0)
+    _check(pair, 128, 128)
+    pair.close()
+
+
+def test_trace_rays_arbitrary(rt):
+    """Rays from inside and behind the mesh (hits behind the origin are legal, Triangle.java has no t>0 test),
+    axis-aligned directions with +0.0 / -0.0 components."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(3000, span=0.2, seed=21)
+    pair = Pair([(v, i, None, rt.ColorInformation((1, 1, 1)))])
+    cam, ocam, ost = pair.cameras(8, 8)
+    rs = np.random.RandomState(5)
+    n = 4000
+    o = rs.uniform(-0.25, 0.25, size=(n, 3)).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    d[:50, 0] = 0.0
+    d[50:100, 1] = -0.0
+    d[100:150, 0] = 0.0
+    d[100:150, 1] = 0.0
+    o[150:200] = 0.0
+    g = cam.getClosestIntersection(o, d)
+    r = pair.oscene.trace(ost, o, d)
+    np.testing.assert_array_equal(g["face"], r["face"])
+    np.testing.assert_array_equal(g["object"], r["object"])
+    np.testing.assert_array_equal(g["w"].view(np.uint32), r["w"].view(np.uint32))
+    hit = r["face"] >= 0
+    assert hit.sum() > 500
+    np.testing.assert_array_equal(g["point"][hit].view(np.uint32), r["point"][hit].view(np.uint32))
+    np.testing.assert_array_equal(g["normal"][hit].view(np.uint32), r["normal"][hit].view(np.uint32))
+    pair.close()
