@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s (primary + shadow) on the Dragon-class workload, 1920x1080, 4 spp, Phong.
+
+A "step" is one frame: every primary sample of the 1080p image, one shadow ray per hit sample,
+shaded, averaged and written.  The scene (flattened hierarchy) is resident in HBM before the timed
+region; the framebuffer stays in HBM.  With N > 1 GPUs (one process per GPU, launched by
+torch.distributed.run) the frame's 16x16-pixel tiles are interleaved over the ranks, the scene is
+replicated, and the step ends with ONE gather of the tiles to rank 0 over RCCL (strong scaling:
+the frame is fixed).  Rays are counted by the kernel, not assumed.
+
+Prints ONE JSON line on rank 0 (see the repository's bench contract) with two extra objects:
+  roofline     -- algorithmic bytes of the render kernel per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline -- the oracle (C restatement of the reference's algorithm, reference visit order) timed
+                  on this host's cores on a bounded sample of the same frame.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_BOX_TEST = 32          # 24 B box + 8 B link per child box tested
+BYTES_PER_TRI_TEST = 48          # 3 x float4 positions
+BYTES_PER_HIT = 48               # 3 x float4 normals per final hit
+BYTES_PER_PIXEL = 16             # f32 RGB + i32 id written
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="dragon", help="stand-in from meshgen.STANFORD")
+    ap.add_argument("--faces", type=int, default=0, help="override the face count (0 = the model's own)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import ray_tracer_amd as rt
+    from ray_tracer_amd import tiles
+
+    cfg = rt.meshgen.STANFORD[args.model]
+    verts, idx = rt.meshgen.stanford_standin(args.model, args.faces or None)
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))          # RayTracer.java:106
+    mesh = rt.TriangleMesh((verts, idx), rt.ColorInformation((0.9, 0.9, 0.9)), True)  # RayTracer.java:122-123
+    t0 = time.time()
+    scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"], device=local_rank)
+    build_s = time.time() - t0
+    W, H = args.width, args.height
+    cam = rt.Camera(scene, args.spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
+
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    hit_id = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    hit_w = torch.zeros((H, W), dtype=torch.float32, device=dev)
+    frame = rt._abi.Frame(rgb.data_ptr(), None, hit_id.data_ptr(), None, hit_w.data_ptr())
+    sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev)
+    stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream
+
+    def step(stats=False):
+        cam.render_device(frame, stream=stream, tile_rank=rank, tile_world=world, tile_size=tiles.DEFAULT_TILE,
+                          collect_stats=stats)
+
+    # counted, not assumed: one instrumented frame
+    step(stats=True)
+    torch.cuda.synchronize()
+    st = cam.frame_stats()
+    counts = torch.tensor([st["primary_rays"], st["shadow_rays"], st["secondary_rays"], st["box_tests"], st["tri_tests"],
+                           st["hits"]], dtype=torch.float64, device=dev)
+    local_counts = counts.clone()
+    if world > 1:
+        dist.all_reduce(counts)
+    primary, shadow, secondary, boxes, tris, hits = [float(x) for x in counts.tolist()]
+    rays_per_frame = primary + shadow + secondary
+
+    for _ in range(args.warmup):
+        step()
+        sharder.gather(rgb, hit_w, hit_id)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        step()
+        ev[k][1].record()
+        sharder.gather(rgb, hit_w, hit_id)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    mrays = rays_per_frame / (elapsed / args.steps) / 1e6
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # roofline of the dominant (only) kernel, this rank's launch
+    lp, ls, lsec, lb, lt, lh = [float(x) for x in local_counts.tolist()]
+    own_pixels = float(sharder.my_pix.ge(0).sum().item())
+    algo_bytes = BYTES_PER_BOX_TEST * lb + BYTES_PER_TRI_TEST * lt + BYTES_PER_HIT * lh + BYTES_PER_PIXEL * own_pixels
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            key = "%s_%dx%d_%dspp_n%d" % (args.model, W, H, args.spp, world)
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "render_kernel",
+                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
+                "bytes_per_ray": round(algo_bytes / max(lp + ls + lsec, 1.0), 1),
+                "box_tests_per_ray": round(lb / max(lp + ls + lsec, 1.0), 2),
+                "tri_tests_per_ray": round(lt / max(lp + ls + lsec, 1.0), 2)}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, verts, idx, cfg, light)
+
+    out = {
+        "metric": "Mrays/sec (primary+shadow) on Dragon 1080p",
+        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: Dragon stand-in (seeded procedural blob, %d faces) %dx%d, %d spp, Phong, "
+                               "primary+shadow" % (idx.shape[0], W, H, args.spp),
+                   "rays_per_frame": int(rays_per_frame), "primary": int(primary), "shadow": int(shadow),
+                   "tile": tiles.DEFAULT_TILE, "parallelism": "tiles%d" % world,
+                   "hierarchy": {k: scene.object_info(0)[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")},
+                   "scene_hbm_bytes": scene.device_bytes(), "scene_build_s": round(build_s, 2)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, verts, idx, cfg, light):
+    """The oracle in reference order (exhaustive both-children traversal), multithreaded, on a bounded
+    sample of the same frame: every k-th pixel in row-major order, all of its samples and shadow rays."""
+    import oracle
+    import ray_tracer_amd as rt
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    osc = oracle.OracleScene([(verts, idx, None, oracle.material(diffuse=(0.9, 0.9, 0.9)))])
+    ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, args.width, args.height)
+    ost = oracle.settings(epsilon=osc.epsilon(), ms=args.spp, lighting=1, seed=2024, light_origin=light.origin,
+                          light_emission=light.emission, light_ambient=light.ambient)
+    # probe at a sparse stride, then choose the stride for the timed sample
+    stride = 257
+    t0 = time.perf_counter()
+    o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    full_s = dt * stride
+    stride = max(1, int(np.ceil(full_s / args.cpu_seconds)))
+    if stride > 1 and stride % 2 == 0:
+        stride += 1   # odd strides walk every column of an even-width image
+    t0 = time.perf_counter()
+    o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
+    dt = time.perf_counter() - t0
+    s = o["stats"]
+    rays = s["primary_rays"] + s["shadow_rays"] + s["secondary_rays"]
+    osc.close()
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "every %d-th pixel of the same %dx%d frame, %d spp + shadow rays (%d rays, %.1f s); "
+                      "C restatement of the Java algorithm in reference visit order, %d pthreads"
+                      % (stride, args.width, args.height, args.spp, rays, dt, cores),
+            "java_present": bool(any(os.path.exists(os.path.join(p, "java")) for p in os.environ.get("PATH", "").split(":")))}
+
+
+if __name__ == "__main__":
+    main()
