@@ -2,6 +2,7 @@
 // set-up (camera constants, BRDF table remap) and HIP memory / launch plumbing.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -71,8 +72,22 @@ struct HostObject {
 
 }   // namespace
 
+// device scratch of one frame pass (layout.h "FRAME SCRATCH")
+struct FrameScratch {
+   size_t cap = 0;        // sample slots
+   bool with_mirror = false;
+   float *samples = nullptr, *rays0 = nullptr, *hits0 = nullptr, *mat0 = nullptr;
+   int32_t *hit_obj0 = nullptr;
+   uint32_t *shadow = nullptr;
+   float *rays1[2] = { nullptr, nullptr };
+   float *hits1 = nullptr;
+   int32_t *hit_obj1 = nullptr;
+   uint64_t bytes = 0;
+};
+
 struct mi355rt_scene {
    int device = 0;
+   int n_cus = 256;
    std::vector<HostObject> objects;
    std::vector<mi355rt_material> materials;
    DevObject *d_objs = nullptr;
@@ -80,17 +95,29 @@ struct mi355rt_scene {
    int32_t n_dirs = 0, n_materials = 0;
    float smin[3], smax[3];   // scene bounds (Scene.java:21-33)
    float abs_max = 0.f;
+   float max_normal_len = 0.f;
+   bool has_mirror = false;
    uint64_t device_bytes = 0;
-   unsigned long long *d_stats = nullptr;   // 6 counters
+   uint32_t *d_counters = nullptr;   // CNT_WORDS
    bool stats_valid = false;
-   // scratch frame for the host-buffer render entry point
+   mi355rt_stats stats_accum {};
+   FrameScratch scratch;
+   // frame buffers of the host-buffer render entry point
    float *d_rgb = nullptr;
    int32_t *d_hit_id = nullptr;
    float *d_hit_w = nullptr;
-   size_t scratch_pixels = 0;
+   size_t frame_pixels = 0;
 };
 
 namespace {
+
+void free_scratch(FrameScratch &fs)
+{
+   void *all[] = { fs.samples, fs.rays0, fs.hits0, fs.mat0, fs.hit_obj0, fs.shadow, fs.rays1[0], fs.rays1[1], fs.hits1, fs.hit_obj1 };
+   for (void *q : all)
+      if (q) (void) hipFree(q);
+   fs = FrameScratch();
+}
 
 void release_scene(mi355rt_scene *s)
 {
@@ -103,10 +130,11 @@ void release_scene(mi355rt_scene *s)
    if (s->d_objs) (void) hipFree(s->d_objs);
    if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
    if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
-   if (s->d_stats) (void) hipFree(s->d_stats);
+   if (s->d_counters) (void) hipFree(s->d_counters);
    if (s->d_rgb) (void) hipFree(s->d_rgb);
    if (s->d_hit_id) (void) hipFree(s->d_hit_id);
    if (s->d_hit_w) (void) hipFree(s->d_hit_w);
+   free_scratch(s->scratch);
    delete s;
 }
 
@@ -131,13 +159,80 @@ int check_settings(const mi355rt_settings *st)
    return MI355RT_OK;
 }
 
-int fill_render_params(const mi355rt_scene *s, const mi355rt_camera *cam, const mi355rt_settings *st, RenderParams &p)
+// a pass renders at most this many sample slots at once (bounds the scratch: ~104 B per slot,
+// ~204 B with mirrors)
+constexpr size_t PASS_SLOTS = (size_t) 1 << 24;
+
+int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror)
+{
+   FrameScratch &fs = s->scratch;
+   if (fs.cap >= cap && (fs.with_mirror || !with_mirror)) return MI355RT_OK;
+   free_scratch(fs);
+   struct Want {
+      void **dst;
+      size_t bytes;
+   };
+   const Want wants[] = {
+      { (void **) &fs.samples, cap * 16 },  { (void **) &fs.rays0, cap * 32 },    { (void **) &fs.hits0, cap * 32 },
+      { (void **) &fs.mat0, cap * 16 },     { (void **) &fs.hit_obj0, cap * 4 },  { (void **) &fs.shadow, cap * 4 },
+      { (void **) &fs.rays1[0], with_mirror ? cap * 32 : 0 }, { (void **) &fs.rays1[1], with_mirror ? cap * 32 : 0 },
+      { (void **) &fs.hits1, with_mirror ? cap * 32 : 0 },    { (void **) &fs.hit_obj1, with_mirror ? cap * 4 : 0 },
+   };
+   for (const Want &w : wants) {
+      if (!w.bytes) continue;
+      hipError_t e = hipMalloc(w.dst, w.bytes);
+      if (e != hipSuccess) {
+         free_scratch(fs);
+         return hip_fail(e, "hipMalloc(frame scratch)");
+      }
+      fs.bytes += w.bytes;
+   }
+   fs.cap = cap;
+   fs.with_mirror = with_mirror;
+   return MI355RT_OK;
+}
+
+// RTStatics.shadowIntersects does a full closest-hit query per object and then asks whether that
+// hit lies before the light (RTStatics.java:626-633).  When the light is farther from the scene's
+// box than the box's own diagonal (with slack), EVERY accepted candidate (w > shadowDistance)
+// satisfies "w > EPSILON && w < distance(hit, light) + EPSILON", so "occluded" is simply "some
+// candidate exists" and the walk may stop at the first one.  Conditions checked here:
+//   * finite scene box; every object's shadowDistance >= EPSILON (so w > shadowDistance => w > EPSILON);
+//   * w <= diag(box) + |N|*EPSILON for any origin on a surface and any hit point in the box, and
+//     distance(hit, light) >= distance(light, box); require distance(light, box) > 1.01 * that bound.
+bool shadow_any_hit_is_exact(const mi355rt_scene *s, const mi355rt_settings *st)
+{
+   if (s->objects.empty()) return false;
+   double diag2 = 0.0, dl2 = 0.0;
+   for (int c = 0; c < 3; c++) {
+      if (!std::isfinite(s->smin[c]) || !std::isfinite(s->smax[c]) || !std::isfinite(st->light_origin[c])) return false;
+      const double e = (double) s->smax[c] - (double) s->smin[c];
+      diag2 += e * e;
+      const double l = st->light_origin[c];
+      const double d = std::fmax(std::fmax((double) s->smin[c] - l, l - (double) s->smax[c]), 0.0);
+      dl2 += d * d;
+   }
+   if (!(st->epsilon >= 0.0f) || !std::isfinite(s->max_normal_len)) return false;
+   for (const HostObject &o : s->objects)
+      if (!(o.shadow_distance >= st->epsilon)) return false;
+   const double reach = std::sqrt(diag2) + 2.0 * (double) s->max_normal_len * (double) st->epsilon + (double) st->epsilon;
+   return std::sqrt(dl2) > 1.01 * reach + 1e-6 * (double) s->abs_max;
+}
+
+int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi355rt_settings *st, FrameArgs &p, long long &n_micro)
 {
    if (!cam) return fail(MI355RT_E_ARG, "camera is null");
    if (int rc = check_settings(st)) return rc;
    if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
    if ((uint64_t) cam->width * (uint64_t) cam->height > (uint64_t) 1 << 30) return fail(MI355RT_E_LIMIT, "image larger than 2^30 pixels");
+   if ((size_t) st->multi_samples * 64 > PASS_SLOTS) return fail(MI355RT_E_LIMIT, "multi_samples too large");
    std::memset(&p, 0, sizeof(p));
+   p.sc.objs = s->d_objs;
+   p.sc.n_objs = (int32_t) s->objects.size();
+   p.sc.epsilon = st->epsilon;
+   p.sc.near_plane = st->near_plane;
+   p.sc.far_plane = st->far_plane;
+   p.sc.scene_abs_max = s->abs_max;
    std::memcpy(p.origin, cam->origin, sizeof(p.origin));
    std::memcpy(p.rot, cam->rotation, sizeof(p.rot));
    // Camera.createImage constants (Camera.java:123-126)
@@ -148,9 +243,6 @@ int fill_render_params(const mi355rt_scene *s, const mi355rt_camera *cam, const 
    p.near_plane_cam = cam->near_plane;
    p.width = cam->width;
    p.height = cam->height;
-   p.epsilon = st->epsilon;
-   p.near_plane = st->near_plane;
-   p.far_plane = st->far_plane;
    p.multi_samples = st->multi_samples;
    p.brdf_samples = st->brdf_samples;
    p.lighting_model = st->lighting_model;
@@ -159,19 +251,17 @@ int fill_render_params(const mi355rt_scene *s, const mi355rt_camera *cam, const 
    std::memcpy(p.light_origin, st->light_origin, sizeof(p.light_origin));
    std::memcpy(p.light_emission, st->light_emission, sizeof(p.light_emission));
    std::memcpy(p.light_ambient, st->light_ambient, sizeof(p.light_ambient));
-   p.n_objs = (int32_t) s->objects.size();
-   p.objs = s->d_objs;
+   p.shadow_any_hit = shadow_any_hit_is_exact(s, st) ? 1 : 0;
    p.brdf_dirs = s->d_brdf_dirs;
    p.brdf_weights = s->d_brdf_weights;
    p.n_dirs = s->n_dirs;
    p.n_materials = s->n_materials;
-   p.scene_abs_max = s->abs_max;
    for (size_t i = 0; i < s->materials.size(); i++) {
       const mi355rt_material &m = s->materials[i];
       if (m.kind == MI355RT_MAT_BRDF && (m.brdf_id < 0 || m.brdf_id >= s->n_materials))
-         return fail(MI355RT_E_ARG, "mesh " + std::to_string(i) + ": BRDF material row " + std::to_string(m.brdf_id) + " is outside the loaded tables (call mi355rt_brdf_tables first)");
+         return fail(MI355RT_E_ARG, "mesh " + std::to_string(i) + ": BRDF material row " + std::to_string(m.brdf_id) +
+                                        " is outside the loaded tables (call mi355rt_brdf_tables first)");
    }
-
    int tile = st->tile_size == 0 ? 16 : st->tile_size;
    int world = st->tile_world == 0 ? 1 : st->tile_world;
    if (tile < 8 || tile % 8 != 0 || tile > 4096) return fail(MI355RT_E_ARG, "tile_size must be a multiple of 8 in [8, 4096]");
@@ -183,11 +273,84 @@ int fill_render_params(const mi355rt_scene *s, const mi355rt_camera *cam, const 
    p.tiles_y = (cam->height + tile - 1) / tile;
    const long long n_tiles = (long long) p.tiles_x * p.tiles_y;
    const long long owned = n_tiles > st->tile_rank ? (n_tiles - st->tile_rank + world - 1) / world : 0;
-   p.n_owned_tiles = (int32_t) owned;
    p.micro_per_tile = (tile / 8) * (tile / 8);
-   const long long n_micro = owned * p.micro_per_tile;
-   if (n_micro > 0x7fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups for one launch");
-   p.n_micro = (int32_t) n_micro;
+   n_micro = owned * p.micro_per_tile;
+   if (n_micro > 0x3fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups");
+   p.stats = st->collect_stats != 0;
+   return MI355RT_OK;
+}
+
+// one frame = passes of at most PASS_SLOTS sample slots, each a run of the kernel pipeline
+int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t stream)
+{
+   if (n_micro == 0) return MI355RT_OK;
+   const size_t slots_per_micro = (size_t) 64 * (size_t) p.multi_samples;
+   const long long micro_per_pass = (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
+   const long long first_pass = std::min(n_micro, micro_per_pass);
+   if (int rc = ensure_scratch(s, (size_t) first_pass * slots_per_micro, s->has_mirror)) return rc;
+   const FrameScratch &fs = s->scratch;
+   p.samples = fs.samples;
+   p.rays0 = fs.rays0;
+   p.hits0 = fs.hits0;
+   p.hit_obj0 = fs.hit_obj0;
+   p.mat0 = fs.mat0;
+   p.shadow = fs.shadow;
+   p.rays1[0] = fs.rays1[0];
+   p.rays1[1] = fs.rays1[1];
+   p.hits1 = fs.hits1;
+   p.hit_obj1 = fs.hit_obj1;
+   p.counters = s->d_counters;
+   if (p.stats) {
+      s->stats_accum = mi355rt_stats {};
+      s->stats_valid = true;
+   }
+
+   for (long long m0 = 0; m0 < n_micro; m0 += micro_per_pass) {
+      const long long m1 = std::min(n_micro, m0 + micro_per_pass);
+      const unsigned long long slots = (unsigned long long) (m1 - m0) * slots_per_micro;
+      p.micro_begin = (int32_t) m0;
+      p.micro_end = (int32_t) m1;
+      HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
+      HIP_TRY(launch_generate(p, stream));
+      int cursor = CNT_CURSOR0;
+      HIP_TRY(launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cursor++, slots, s->n_cus, p.stats ? 2 : 0, stream));
+      HIP_TRY(launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream));
+      if (s->has_mirror) {
+         // mirror bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
+         int cur = 0;
+         for (int bounce = 0; bounce <= p.max_mirror_bounces; bounce++) {
+            uint32_t n_sec = 0;
+            HIP_TRY(hipMemcpyAsync(&n_sec, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), sizeof(n_sec), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (n_sec == 0) break;
+            const int cur_cnt = cur == 0 ? CNT_SEC_A : CNT_SEC_B, nxt_cnt = cur == 0 ? CNT_SEC_B : CNT_SEC_A;
+            if (cursor >= CNT_STATS) cursor = CNT_CURSOR0 + 2;
+            HIP_TRY(hipMemsetAsync(p.counters + cursor, 0, sizeof(uint32_t), stream));
+            HIP_TRY(hipMemsetAsync(p.counters + nxt_cnt, 0, sizeof(uint32_t), stream));
+            HIP_TRY(launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cursor++, n_sec, s->n_cus, p.stats ? 1 : 0, stream));
+            HIP_TRY(launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream));
+            cur ^= 1;
+         }
+      }
+      if (p.lighting_model == MI355RT_LIGHTING_PHONG) {
+         if (cursor >= CNT_STATS) cursor = CNT_CURSOR0 + 2;
+         HIP_TRY(hipMemsetAsync(p.counters + cursor, 0, sizeof(uint32_t), stream));
+         HIP_TRY(launch_shadow(p, cursor++, slots, s->n_cus, stream));
+         HIP_TRY(launch_phong(p, slots, s->n_cus, stream));
+      }
+      HIP_TRY(launch_resolve(p, stream));
+      if (p.stats) {
+         unsigned long long h[6];
+         HIP_TRY(hipMemcpyAsync(h, p.counters + CNT_STATS, sizeof(h), hipMemcpyDeviceToHost, stream));
+         HIP_TRY(hipStreamSynchronize(stream));
+         s->stats_accum.primary_rays += h[0];
+         s->stats_accum.shadow_rays += h[1];
+         s->stats_accum.secondary_rays += h[2];
+         s->stats_accum.box_tests += h[3];
+         s->stats_accum.tri_tests += h[4];
+         s->stats_accum.hits += h[5];
+      }
+   }
    return MI355RT_OK;
 }
 
@@ -276,6 +439,12 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
          }
          s->objects.emplace_back();
          s->materials.push_back(md.material);
+         if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
+         for (size_t v = 0; v + 2 < bo_out.normals.size(); v += 3) {
+            const float *nv = bo_out.normals.data() + v;
+            const float len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+            if (!(len <= s->max_normal_len)) s->max_normal_len = len;   // a NaN length sticks (and disables the any-hit shortcut)
+         }
          HostObject &ho = s->objects.back();
          std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
          std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
@@ -326,11 +495,13 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
       release_scene(s);
       return rc;
    }
-   hipError_t e = hipMalloc((void **) &s->d_stats, 6 * sizeof(unsigned long long));
+   hipError_t e = hipMalloc((void **) &s->d_counters, CNT_WORDS * sizeof(uint32_t));
    if (e != hipSuccess) {
       release_scene(s);
-      return hip_fail(e, "hipMalloc(stats)");
+      return hip_fail(e, "hipMalloc(counters)");
    }
+   int cus = 0;
+   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
    *out = s;
    return MI355RT_OK;
 }
@@ -446,24 +617,17 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
                           void *hip_stream)
 {
    if (!scene || !frame) return fail(MI355RT_E_ARG, "null argument");
-   RenderParams p;
-   if (int rc = fill_render_params(scene, cam, settings, p)) return rc;
+   FrameArgs p;
+   long long n_micro = 0;
+   if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
    DeviceScope scope(scene->device);
    if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   hipStream_t stream = (hipStream_t) hip_stream;
    p.rgb = frame->rgb;
    p.argb8 = frame->argb8;
    p.hit_id = frame->hit_id;
    p.hit_obj = frame->hit_obj;
    p.hit_w = frame->hit_w;
-   const bool stats = settings->collect_stats != 0;
-   if (stats) {
-      HIP_TRY(hipMemsetAsync(scene->d_stats, 0, 6 * sizeof(unsigned long long), stream));
-      p.stats = scene->d_stats;
-      scene->stats_valid = true;
-   }
-   HIP_TRY(launch_render(p, stats, stream));
-   return MI355RT_OK;
+   return run_frame(scene, p, n_micro, (hipStream_t) hip_stream);
 }
 
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
@@ -474,18 +638,18 @@ int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355r
    DeviceScope scope(scene->device);
    if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
    const size_t pixels = (size_t) cam->width * (size_t) cam->height;
-   if (pixels > scene->scratch_pixels) {
+   if (pixels > scene->frame_pixels) {
       if (scene->d_rgb) (void) hipFree(scene->d_rgb);
       if (scene->d_hit_id) (void) hipFree(scene->d_hit_id);
       if (scene->d_hit_w) (void) hipFree(scene->d_hit_w);
       scene->d_rgb = nullptr;
       scene->d_hit_id = nullptr;
       scene->d_hit_w = nullptr;
-      scene->scratch_pixels = 0;
+      scene->frame_pixels = 0;
       HIP_TRY(hipMalloc((void **) &scene->d_rgb, pixels * 3 * sizeof(float)));
       HIP_TRY(hipMalloc((void **) &scene->d_hit_id, pixels * sizeof(int32_t)));
       HIP_TRY(hipMalloc((void **) &scene->d_hit_w, pixels * sizeof(float)));
-      scene->scratch_pixels = pixels;
+      scene->frame_pixels = pixels;
    }
    // tiles owned by other ranks stay zero
    HIP_TRY(hipMemsetAsync(scene->d_rgb, 0, pixels * 3 * sizeof(float), nullptr));
@@ -508,17 +672,7 @@ int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
 {
    if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
    if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   unsigned long long h[6];
-   HIP_TRY(hipDeviceSynchronize());
-   HIP_TRY(hipMemcpy(h, scene->d_stats, sizeof(h), hipMemcpyDeviceToHost));
-   out->primary_rays = h[0];
-   out->shadow_rays = h[1];
-   out->secondary_rays = h[2];
-   out->box_tests = h[3];
-   out->tri_tests = h[4];
-   out->hits = h[5];
+   *out = scene->stats_accum;   // run_frame reads the counters back at the end of each pass
    return MI355RT_OK;
 }
 
@@ -528,46 +682,53 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    if (!scene || !settings) return fail(MI355RT_E_ARG, "null argument");
    if (n == 0) return MI355RT_OK;
    if (!origins || !directions) return fail(MI355RT_E_ARG, "null ray arrays");
-   if (n > ((uint64_t) 1 << 31)) return fail(MI355RT_E_LIMIT, "more than 2^31 rays in one call");
+   if (n > ((uint64_t) 1 << 30)) return fail(MI355RT_E_LIMIT, "more than 2^30 rays in one call");
    DeviceScope scope(scene->device);
    if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
 
    struct Buffers {
-      void *p[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+      void *p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
       ~Buffers()
       {
          for (void *q : p)
             if (q) (void) hipFree(q);
       }
    } buf;
-   const size_t sizes[7] = { n * 3 * sizeof(float), n * 3 * sizeof(float), n * sizeof(int32_t), n * sizeof(int32_t),
-                             n * sizeof(float),     n * 3 * sizeof(float), n * 3 * sizeof(float) };
-   for (int i = 0; i < 7; i++) HIP_TRY(hipMalloc(&buf.p[i], sizes[i]));
+   // 0 origins, 1 dirs, 2 rays, 3 hits, 4 hit_obj, 5 out_id, 6 out_obj, 7 out_w, 8 out_point, 9 out_normal
+   const size_t sizes[10] = { n * 12, n * 12, n * 32, n * 32, n * 4, n * 4, n * 4, n * 4, n * 12, n * 12 };
+   for (int i = 0; i < 10; i++) HIP_TRY(hipMalloc(&buf.p[i], sizes[i]));
    HIP_TRY(hipMemcpy(buf.p[0], origins, sizes[0], hipMemcpyHostToDevice));
    HIP_TRY(hipMemcpy(buf.p[1], directions, sizes[1], hipMemcpyHostToDevice));
-   TraceParams tp;
-   std::memset(&tp, 0, sizeof(tp));
-   tp.epsilon = settings->epsilon;
-   tp.near_plane = settings->near_plane;
-   tp.far_plane = settings->far_plane;
-   tp.n_objs = (int32_t) scene->objects.size();
-   tp.objs = scene->d_objs;
-   tp.scene_abs_max = scene->abs_max;
-   tp.n = n;
-   tp.origins = (const float *) buf.p[0];
-   tp.dirs = (const float *) buf.p[1];
-   tp.hit_id = (int32_t *) buf.p[2];
-   tp.hit_obj = (int32_t *) buf.p[3];
-   tp.hit_w = (float *) buf.p[4];
-   tp.hit_point = (float *) buf.p[5];
-   tp.hit_normal = (float *) buf.p[6];
-   HIP_TRY(launch_trace_rays(tp, nullptr));
+   TraceBatchArgs a;
+   std::memset(&a, 0, sizeof(a));
+   a.sc.objs = scene->d_objs;
+   a.sc.n_objs = (int32_t) scene->objects.size();
+   a.sc.epsilon = settings->epsilon;
+   a.sc.near_plane = settings->near_plane;
+   a.sc.far_plane = settings->far_plane;
+   a.sc.scene_abs_max = scene->abs_max;
+   a.n = (uint32_t) n;
+   a.origins = (const float *) buf.p[0];
+   a.dirs = (const float *) buf.p[1];
+   a.rays = (float *) buf.p[2];
+   a.hits = (float *) buf.p[3];
+   a.hit_obj = (int32_t *) buf.p[4];
+   a.counters = scene->d_counters;
+   a.out_id = (int32_t *) buf.p[5];
+   a.out_obj = (int32_t *) buf.p[6];
+   a.out_w = (float *) buf.p[7];
+   a.out_point = (float *) buf.p[8];
+   a.out_normal = (float *) buf.p[9];
+   HIP_TRY(hipMemsetAsync(scene->d_counters, 0, CNT_WORDS * sizeof(uint32_t), nullptr));
+   HIP_TRY(launch_batch_pack(a, nullptr));
+   HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, n, scene->n_cus, 0, nullptr));
+   HIP_TRY(launch_batch_unpack(a, nullptr));
    HIP_TRY(hipStreamSynchronize(nullptr));
-   if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[2], sizes[2], hipMemcpyDeviceToHost));
-   if (hit_obj) HIP_TRY(hipMemcpy(hit_obj, buf.p[3], sizes[3], hipMemcpyDeviceToHost));
-   if (hit_w) HIP_TRY(hipMemcpy(hit_w, buf.p[4], sizes[4], hipMemcpyDeviceToHost));
-   if (hit_point) HIP_TRY(hipMemcpy(hit_point, buf.p[5], sizes[5], hipMemcpyDeviceToHost));
-   if (hit_normal) HIP_TRY(hipMemcpy(hit_normal, buf.p[6], sizes[6], hipMemcpyDeviceToHost));
+   if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[5], sizes[5], hipMemcpyDeviceToHost));
+   if (hit_obj) HIP_TRY(hipMemcpy(hit_obj, buf.p[6], sizes[6], hipMemcpyDeviceToHost));
+   if (hit_w) HIP_TRY(hipMemcpy(hit_w, buf.p[7], sizes[7], hipMemcpyDeviceToHost));
+   if (hit_point) HIP_TRY(hipMemcpy(hit_point, buf.p[8], sizes[8], hipMemcpyDeviceToHost));
+   if (hit_normal) HIP_TRY(hipMemcpy(hit_normal, buf.p[9], sizes[9], hipMemcpyDeviceToHost));
    return MI355RT_OK;
 }
 

@@ -6,8 +6,17 @@
 
 namespace mi355rt {
 
-hipError_t launch_render(const RenderParams &p, bool stats, hipStream_t stream);
-hipError_t launch_trace_rays(const TraceParams &p, hipStream_t stream);
+hipError_t launch_generate(const FrameArgs &p, hipStream_t stream);
+// stats: 0 none, 1 count boxes / triangles, 2 also count hits (the primary queue)
+hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
+                        int cursor_index, unsigned long long max_items, int n_cus, int stats, hipStream_t stream);
+hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const float *hits, const int32_t *hit_obj, int count_index,
+                        float *rays_next, int next_count_index, unsigned long long max_items, int n_cus, hipStream_t stream);
+hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long long max_items, int n_cus, hipStream_t stream);
+hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream);
+hipError_t launch_resolve(const FrameArgs &p, hipStream_t stream);
+hipError_t launch_batch_pack(const TraceBatchArgs &a, hipStream_t stream);
+hipError_t launch_batch_unpack(const TraceBatchArgs &a, hipStream_t stream);
 hipError_t launch_arith_probe(unsigned long long n, const float *a, const float *b, float *out_div, float *out_sqrt,
                               float *out_rnorm, float *out_pow, hipStream_t stream);
 

@@ -1,6 +1,7 @@
-// layout.h -- HBM data layout shared by the host builder and the HIP kernels.
+// layout.h -- HBM data layout shared by the host side and the HIP kernels of libmi355rt.
 //
-// One mesh object (= one KDTree of the reference, bounds/KDTree.java) is three arrays:
+// SCENE (read-only during a frame).  One mesh object (= one KDTree of the reference,
+// bounds/KDTree.java) is three arrays:
 //
 //   nodes : one 64-byte record per INTERNAL node of the reference hierarchy, in DFS pre-order.
 //           A record carries the boxes and links of BOTH children, so one 4 x 128-bit fetch
@@ -18,14 +19,24 @@
 //           Because leaves are laid out in DFS order, the first-slot index of a leaf is also the
 //           leaf's rank in the reference's fold order (the tie rule of KDNode.java:105,114).
 //   fnrm  : 48 bytes per FACE (not per slot): the three vertex normals, fetched once per final hit.
+//
+// FRAME SCRATCH (per scene handle, sized for one pass of at most `cap` samples).  The frame is a
+// wavefront pipeline over compacted queues; every record is 16-byte aligned for 128-bit access:
+//
+//   samples : float4 per sample slot -- the sample's colour (RenderThread's colors[j])
+//   rays    : 2 x float4 per queued ray { o.xyz, bits(slot) } { d.xyz, bits(aux) }
+//   hits    : 2 x float4 per queued ray { P.xyz, w } { N.xyz, bits(face) }, plus hit_obj int (-1 miss)
+//   mat     : float4 per PRIMARY queue entry { material colour rgb, bits(occluded) }
+//   shadow  : u32 per shadow ray = index of its primary queue entry
+//   counters: queue sizes and the work cursors of the persistent trace launches
 #pragma once
 #include <stdint.h>
 
 namespace mi355rt {
 
 constexpr int32_t LINK_NONE = -1;
-constexpr int MAX_TREE_DEPTH = 30;   // build_opts.max_depth limit; traversal stack holds depth+2
-constexpr int STACK_SLOTS = 32;
+constexpr int MAX_TREE_DEPTH = 22;   // build_opts.max_depth limit (the reference uses 20)
+constexpr int STACK_SLOTS = 24;      // >= MAX_TREE_DEPTH + 2
 constexpr int MAX_OBJECTS = 64;
 constexpr int BLOCK_THREADS = 256;
 
@@ -48,50 +59,79 @@ struct DevObject {
    const void *tris;    // float4[3 * n_slots]
    const void *fnrm;    // float4[3 * n_faces]
    float bmin[3], bmax[3];
-   int32_t root_link, root_cnt;   // root_cnt > 0 (or n_faces == 0): the root itself is a leaf
+   int32_t root_link, root_cnt;
    int32_t root_is_leaf;
    float shadow_distance;
    DevMaterial mat;
    int32_t pad_[2];
 };
 
-struct RenderParams {
+// what every kernel needs to walk the scene
+struct SceneArgs {
+   const DevObject *objs;
+   int32_t n_objs;
+   float epsilon, near_plane, far_plane;
+   float scene_abs_max;   // max |coordinate| of the scene bounds (prune margin)
+};
+
+// counters[] slots
+enum {
+   CNT_Q0 = 0,        // primary queue size
+   CNT_SHADOW = 1,    // shadow list size
+   CNT_SEC_A = 2,     // secondary queues (ping-pong)
+   CNT_SEC_B = 3,
+   CNT_CURSOR0 = 4,   // work cursors, one per persistent launch (CNT_CURSOR0 + k)
+   CNT_STATS = 16,    // 6 x 64-bit stats counters start here (u32 pairs)
+   CNT_WORDS = 32
+};
+
+struct FrameArgs {
+   SceneArgs sc;
    // camera (Camera.java:40-94, 123-126)
    float origin[3];
    float rot[9];
    float x_min, y_min, x_inc, y_inc, near_plane_cam;
    int32_t width, height;
    // settings
-   float epsilon, near_plane, far_plane;
    int32_t multi_samples, brdf_samples, lighting_model, max_mirror_bounces;
    uint64_t rng_seed;
    float light_origin[3], light_emission[3], light_ambient[3];
-   // scene
-   int32_t n_objs;
-   const DevObject *objs;
+   int32_t shadow_any_hit;   // host-proven: any accepted hit occludes (see api.cpp)
    const float *brdf_dirs;      // n_dirs * 3, remapped
    const float *brdf_weights;   // n_materials * n_dirs
    int32_t n_dirs, n_materials;
-   float scene_abs_max;         // max |coordinate| over the scene bounds (prune margin)
-   // tiles
-   int32_t tile_size, tile_rank, tile_world, tiles_x, tiles_y, n_owned_tiles, micro_per_tile, n_micro;
+   // tiles: this pass covers 8x8 pixel groups [micro_begin, micro_end) of the rank's enumeration
+   int32_t tile_size, tile_rank, tile_world, tiles_x, tiles_y, micro_per_tile;
+   int32_t micro_begin, micro_end;
+   // scratch
+   float *samples;      // float4[cap]
+   float *rays0;        // 2 x float4[cap]   primary queue
+   float *hits0;        // 2 x float4[cap]
+   int32_t *hit_obj0;   // [cap]
+   float *mat0;         // float4[cap]
+   uint32_t *shadow;    // [cap]
+   float *rays1[2];     // secondary queues (null when the scene has no mirror)
+   float *hits1;        // 2 x float4[cap]
+   int32_t *hit_obj1;
+   uint32_t *counters;  // CNT_WORDS
    // outputs
    float *rgb;
    uint32_t *argb8;
    int32_t *hit_id, *hit_obj;
    float *hit_w;
-   unsigned long long *stats;   // 6 counters or nullptr
+   int32_t stats;
 };
 
-struct TraceParams {
-   float epsilon, near_plane, far_plane;
-   int32_t n_objs;
-   const DevObject *objs;
-   float scene_abs_max;
-   uint64_t n;
-   const float *origins, *dirs;
-   int32_t *hit_id, *hit_obj;
-   float *hit_w, *hit_point, *hit_normal;
+struct TraceBatchArgs {   // mi355rt_trace_rays
+   SceneArgs sc;
+   uint32_t n;
+   const float *origins, *dirs;   // n*3 each (user layout)
+   float *rays;                   // 2 x float4[n]
+   float *hits;                   // 2 x float4[n]
+   int32_t *hit_obj;              // [n]
+   uint32_t *counters;
+   int32_t *out_id, *out_obj;
+   float *out_w, *out_point, *out_normal;
 };
 
 }   // namespace mi355rt

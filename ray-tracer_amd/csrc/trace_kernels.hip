@@ -1,27 +1,29 @@
-// trace_kernels.hip -- gfx950 kernels for the per-pixel trace loop.
+// trace_kernels.hip -- gfx950 kernels for the per-pixel trace loop, as a wavefront pipeline:
+//
+//   generate   one lane per (pixel, sample): primary ray (RenderThread.java:39-47); rays that miss
+//              every object's root box are resolved on the spot, the rest are compacted into Q0
+//   trace      persistent wave64s pull 64-ray batches from a queue and find the closest hit
+//              (Camera.getClosestIntersection over KDTree/KDNode.getChildIntersection)
+//   shade      material colour of each hit (ColorInformation / BRDFMaterial / ReflectionMaterial);
+//              mirrors push a bounce ray into the secondary queue, lit hits push a shadow ray
+//   shadow     same traversal with RTStatics.shadowIntersects' rule, one flag per path
+//   phong      PhongLightingModel.getPixelColor's combine -> the sample's colour
+//   resolve    RTStatics.computeColorAverage in sample order + Camera.setPixel
 //
 // Compiled with -ffp-contract=off: the reference is Java, which never fuses a*b+c, and hit ids are
 // compared bit-exactly.  f32 divide and sqrt are the correctly rounded forms (hipcc default
 // -fhip-fp32-correctly-rounded-divide-sqrt); Vector3f.normalize's (float)(1.0/Math.sqrt((double)s))
 // is done in f64 as written.
 //
-// Reference semantics carried over (paths under /root/reference/src/stephen/ranger/ar/):
-//   slab test        RTStatics.aabbIntersection            RTStatics.java:102-158
-//   triangle test    Triangle.intersectsTriangle           sceneObjects/Triangle.java:85-133
-//   leaf / node fold KDNode.getChildIntersection           bounds/KDNode.java:92-123
-//   object fold      Camera.getClosestIntersection         Camera.java:193-215
-//   shadow test      RTStatics.shadowIntersects            RTStatics.java:617-639
-//   shading          PhongLightingModel / BRDFMaterial / ReflectionMaterial
-//   pixel loop       RenderThread.run, Camera.setPixel     RenderThread.java:30-69, Camera.java:96-108
-//
-// What is NOT carried over is the visit order.  The reference visits every child whose box passes
-// the slab test, in left/right order, with no early-out.  Here children are visited nearest-first
-// and a subtree is skipped when the distance from the ray ORIGIN to its box exceeds the best hit
-// distance so far (plus a margin).  That is exact because the reference's hit distance is the
-// Euclidean distance from the origin to an interpolated point inside the triangle's bounding box
-// (Triangle.java:126-130), and every box on the path to a leaf contains that box.  The reference's
-// order-dependent tie rule (equal distance: the later leaf in left-to-right order wins, within a
-// leaf the earlier face wins) is restated order-independently on (distance, first-slot-of-leaf).
+// What is NOT carried over from the reference is the visit order.  The reference visits every
+// child whose box passes the slab test, left then right, with no early-out.  Here children are
+// visited nearest-first and a subtree is skipped when the distance from the ray ORIGIN to its box
+// exceeds the best hit distance so far (plus a margin).  That is exact because the reference's hit
+// distance is the Euclidean distance from the origin to an interpolated point inside the
+// triangle's bounding box (Triangle.java:126-130), and every box on the path to a leaf contains
+// that box.  The reference's order-dependent tie rule (equal distance: the later leaf in
+// left-to-right order wins, within a leaf the earlier face wins; KDNode.java:105,114) is restated
+// order-independently on (distance, first-slot-of-leaf).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -77,25 +79,20 @@ struct Ray {
    float abs_margin;
 };
 
-struct Consts {
-   float eps, nearp, farp;
-};
+__device__ __forceinline__ void make_ray(Ray &r, V3 o, V3 d, float scene_abs_max)
+{
+   r.o = o;
+   r.d = d;
+   r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+   r.abs_margin = 1e-5f * (scene_abs_max + fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+}
 
-struct Counters {
-   unsigned box, tri;
-};
-
-struct ObjHit {
-   int face;       // < 0: none
-   unsigned key;   // first slot of the leaf that produced it
-   float w, px, py, pz, u, v;
-};
-
-// RTStatics.aabbIntersection with 1/direction hoisted out (same value on every call for one ray).
-// Written branch-free: after a "return false" nothing else is observable, so evaluating the rest is
-// equivalent.  Every comparison is the reference's own (NaNs fall through exactly as they do there).
-__device__ __forceinline__ bool slab_test(const Ray &r, const Consts &k, float lox, float loy, float loz, float hix, float hiy,
-                                          float hiz, float &t_enter)
+// RTStatics.aabbIntersection (RTStatics.java:102-158) with 1/direction hoisted out (same value on
+// every call for one ray).  Branch-free: after a "return false" nothing else is observable, so
+// evaluating the rest is equivalent.  Every comparison is the reference's own, so NaNs fall
+// through exactly as they do there.
+__device__ __forceinline__ bool slab_test(const Ray &r, float nearp, float farp, float lox, float loy, float loz, float hix,
+                                          float hiy, float hiz, float &t_enter)
 {
    float txmin, txmax, tymin, tymax, tzmin, tzmax;
    if (r.inv.x >= 0) {
@@ -126,7 +123,7 @@ __device__ __forceinline__ bool slab_test(const Ray &r, const Consts &k, float l
    if (tzmin > txmin) txmin = tzmin;
    if (tzmax < txmax) txmax = tzmax;
    t_enter = txmin;
-   return ok && (txmin < k.farp) && (txmax > k.nearp);
+   return ok && (txmin < farp) && (txmax > nearp);
 }
 
 // Squared distance from the ray origin to a box; NaN terms are ignored (=> smaller => less pruning).
@@ -144,69 +141,83 @@ __device__ __forceinline__ float prune_limit2(const Ray &r, float w)
    return lim * lim;
 }
 
+// Triangle.intersectsTriangle (sceneObjects/Triangle.java:85-133) on one leaf slot.
+// Returns false where the reference returns null; otherwise the barycentrics, the interpolated
+// point and its distance from the origin (returnValue[6]).
+__device__ __forceinline__ bool tri_test(const float4 A, const float4 B, const float4 C, const Ray &r, float eps, float &u, float &v,
+                                         V3 &P, float &dist)
+{
+   const V3 p0 = mk3(A.x, A.y, A.z);
+   const V3 e1 = sub3(mk3(B.x, B.y, B.z), p0);
+   const V3 e2 = sub3(mk3(C.x, C.y, C.z), p0);
+   const V3 p = cross3(r.d, e2);
+   const float divisor = dot3(p, e1);
+   if ((divisor < eps) && (divisor > -eps)) return false;
+   const V3 T = sub3(r.o, p0);
+   const V3 q = cross3(T, e1);
+   u = dot3(p, T) / divisor;
+   if ((u < 0) || (u > 1)) return false;
+   v = dot3(q, r.d) / divisor;
+   if ((v < 0) || (v + u > 1)) return false;
+   const float wb = 1.0f - u - v;
+   P = mk3(wb * A.x + u * B.x + v * C.x, wb * A.y + u * B.y + v * C.y, wb * A.z + u * B.z + v * C.z);
+   dist = distance3(r.o, P);
+   return true;
+}
+
+// the running best of one object: distance, winning slot, first slot of its leaf
+struct Best {
+   float w;
+   int slot;   // < 0: none
+   int key;
+};
+
 // All faces of one leaf (KDNode.java:110-118) folded into the object's best hit.
-template <bool STATS>
-__device__ __forceinline__ void leaf_faces(const float4 *__restrict__ tris, int link, int cnt, const Ray &r, const Consts &k,
-                                           float shadow_distance, ObjHit &best, float &lim2, Counters &ctr)
+template <bool STATS, bool ANY>
+__device__ __forceinline__ void leaf_faces(const float4 *__restrict__ tris, int link, int cnt, const Ray &r, float eps,
+                                           float shadow_distance, Best &best, float &lim2, unsigned &n_tri)
 {
    for (int s = 0; s < cnt; ++s) {
       const float4 *t = tris + 3 * (size_t) (link + s);
       const float4 A = t[0], B = t[1], C = t[2];
-      if (STATS) ctr.tri++;
-      const V3 p0 = mk3(A.x, A.y, A.z);
-      const V3 e1 = sub3(mk3(B.x, B.y, B.z), p0);
-      const V3 e2 = sub3(mk3(C.x, C.y, C.z), p0);
-      const V3 p = cross3(r.d, e2);
-      const float divisor = dot3(p, e1);
-      if ((divisor < k.eps) && (divisor > -k.eps)) continue;
-      const V3 T = sub3(r.o, p0);
-      const V3 q = cross3(T, e1);
-      const float u = dot3(p, T) / divisor;
-      if ((u < 0) || (u > 1)) continue;
-      const float v = dot3(q, r.d) / divisor;
-      if ((v < 0) || (v + u > 1)) continue;
-      const float wb = 1.0f - u - v;
-      const float hx = wb * A.x + u * B.x + v * C.x;
-      const float hy = wb * A.y + u * B.y + v * C.y;
-      const float hz = wb * A.z + u * B.z + v * C.z;
-      const float dist = distance3(r.o, mk3(hx, hy, hz));
+      if (STATS) n_tri++;
+      float u, v, dist;
+      V3 P;
+      if (!tri_test(A, B, C, r, eps, u, v, P, dist)) continue;
       if (!(dist > shadow_distance)) continue;
-      if (best.face < 0 || dist < best.w || (dist == best.w && (unsigned) link > best.key)) {
-         best.face = __float_as_int(A.w);
-         best.key = (unsigned) link;
+      if (best.slot < 0 || dist < best.w || (dist == best.w && link > best.key)) {
          best.w = dist;
-         best.px = hx;
-         best.py = hy;
-         best.pz = hz;
-         best.u = u;
-         best.v = v;
-         const float l2 = prune_limit2(r, dist);
-         lim2 = fminf(lim2, l2);
+         best.slot = link + s;
+         best.key = link;
+         lim2 = fminf(lim2, prune_limit2(r, dist));
+         if (ANY) return;
       }
    }
 }
 
 // Closest accepted hit of one object = KDTree.getChildIntersection (bounds/KDTree.java:59-65).
-// `lim2_in` is an external squared prune limit (infinity when there is none).
-template <bool STATS>
-__device__ __forceinline__ void traverse_object(const DevObject &ob, const Ray &r, const Consts &k, bool want, float lim2_in,
-                                                ObjHit &best, int *__restrict__ stack, Counters &ctr)
+// `lim2_in` is an external squared prune limit (infinity when there is none).  With ANY the walk
+// stops at the first accepted candidate (only used where the host proved that equivalent).
+template <bool STATS, bool ANY>
+__device__ __forceinline__ void traverse_object(const DevObject &ob, const Ray &r, const SceneArgs &sc, bool want, float lim2_in,
+                                                Best &best, int *__restrict__ stack, unsigned &n_box, unsigned &n_tri)
 {
-   best.face = -1;
-   best.key = 0;
    best.w = 0.0f;
-   best.px = best.py = best.pz = best.u = best.v = 0.0f;
+   best.slot = -1;
+   best.key = 0;
    float lim2 = lim2_in;
    int sp = 0;
    const float4 *__restrict__ nodes = (const float4 *) ob.nodes;
    const float4 *__restrict__ tris = (const float4 *) ob.tris;
+   const float nearp = sc.near_plane, farp = sc.far_plane, eps = sc.epsilon;
+   const float sd = ob.shadow_distance;
 
    if (want) {
       float te;
-      if (STATS) ctr.box++;
-      if (slab_test(r, k, ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], te)) {
+      if (STATS) n_box++;
+      if (slab_test(r, nearp, farp, ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], te)) {
          if (ob.root_is_leaf) {
-            leaf_faces<STATS>(tris, ob.root_link, ob.root_cnt, r, k, ob.shadow_distance, best, lim2, ctr);
+            leaf_faces<STATS, ANY>(tris, ob.root_link, ob.root_cnt, r, eps, sd, best, lim2, n_tri);
          } else {
             stack[0] = 0;
             sp = 1;
@@ -223,12 +234,12 @@ __device__ __forceinline__ void traverse_object(const DevObject &ob, const Ray &
       float tl = 0.0f, tr = 0.0f;
       bool lok = false, rok = false;
       if (d.x != LINK_NONE) {
-         if (STATS) ctr.box++;
-         lok = slab_test(r, k, a.x, a.y, a.z, a.w, b.x, b.y, tl) && !(origin_box_dist2(r, a.x, a.y, a.z, a.w, b.x, b.y) > lim2);
+         if (STATS) n_box++;
+         lok = slab_test(r, nearp, farp, a.x, a.y, a.z, a.w, b.x, b.y, tl) && !(origin_box_dist2(r, a.x, a.y, a.z, a.w, b.x, b.y) > lim2);
       }
       if (d.y != LINK_NONE) {
-         if (STATS) ctr.box++;
-         rok = slab_test(r, k, b.z, b.w, c.x, c.y, c.z, c.w, tr) && !(origin_box_dist2(r, b.z, b.w, c.x, c.y, c.z, c.w) > lim2);
+         if (STATS) n_box++;
+         rok = slab_test(r, nearp, farp, b.z, b.w, c.x, c.y, c.z, c.w, tr) && !(origin_box_dist2(r, b.z, b.w, c.x, c.y, c.z, c.w) > lim2);
       }
       // nearest child first; `swap` only chooses an order, never whether a child is visited
       const bool swap = lok && rok && (tr < tl);
@@ -236,8 +247,10 @@ __device__ __forceinline__ void traverse_object(const DevObject &ob, const Ray &
       const int f_link = swap ? d.x : d.y, f_cnt = swap ? d.z : d.w;
       const bool n_ok = swap ? rok : lok, f_ok = swap ? lok : rok;
       // leaf children are tested on the spot (they are small); internal children go on the stack
-      if (n_ok && n_cnt > 0) leaf_faces<STATS>(tris, n_link, n_cnt, r, k, ob.shadow_distance, best, lim2, ctr);
-      if (f_ok && f_cnt > 0) leaf_faces<STATS>(tris, f_link, f_cnt, r, k, ob.shadow_distance, best, lim2, ctr);
+      if (n_ok && n_cnt > 0) leaf_faces<STATS, ANY>(tris, n_link, n_cnt, r, eps, sd, best, lim2, n_tri);
+      if (ANY && best.slot >= 0) break;
+      if (f_ok && f_cnt > 0) leaf_faces<STATS, ANY>(tris, f_link, f_cnt, r, eps, sd, best, lim2, n_tri);
+      if (ANY && best.slot >= 0) break;
       if (f_ok && f_cnt == 0) {
          stack[sp * BLOCK_THREADS] = f_link;
          ++sp;
@@ -249,21 +262,39 @@ __device__ __forceinline__ void traverse_object(const DevObject &ob, const Ray &
    }
 }
 
-// interpolated normal of a hit: w*n0 + u*n1 + v*n2 (Triangle.java:128-129), not renormalised
-__device__ __forceinline__ V3 hit_normal(const DevObject *objs, int obj, const ObjHit &h)
+// a wave takes the next 64 queue entries; false once the queue is drained (every wave gets here)
+__device__ __forceinline__ bool next_batch(unsigned *cursor, unsigned count, unsigned &base)
 {
-   const float4 *fn = (const float4 *) objs[obj].fnrm + 3 * (size_t) h.face;
-   const float4 n0 = fn[0], n1 = fn[1], n2 = fn[2];
-   const float wb = 1.0f - h.u - h.v;
-   return mk3(wb * n0.x + h.u * n1.x + h.v * n2.x, wb * n0.y + h.u * n1.y + h.v * n2.y, wb * n0.z + h.u * n1.z + h.v * n2.z);
+   unsigned b = 0;
+   if ((threadIdx.x & 63) == 0) b = atomicAdd(cursor, 64u);
+   base = (unsigned) __builtin_amdgcn_readfirstlane((int) b);
+   return base < count;
 }
 
-__device__ __forceinline__ void make_ray(Ray &r, V3 o, V3 d, float scene_abs_max)
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
-   r.o = o;
-   r.d = d;
-   r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-   r.abs_margin = 1e-5f * (scene_abs_max + fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
+   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+   return v;
+}
+
+__device__ __forceinline__ void add_stat(uint32_t *counters, int which, unsigned v)
+{
+   const unsigned long long s = wave_sum((unsigned long long) v);
+   if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long *) (counters + CNT_STATS) + which, s);
+}
+enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, ST_HITS = 5 };
+
+// appends one record per lane with `push` set; returns the lane's index (wave-aggregated atomic)
+__device__ __forceinline__ unsigned queue_push(unsigned *count, bool push)
+{
+   const unsigned long long mask = __ballot(push);
+   if (mask == 0ull) return 0u;
+   const int lane = threadIdx.x & 63;
+   const int leader = __ffsll((unsigned long long) mask) - 1;
+   unsigned base = 0;
+   if (lane == leader) base = atomicAdd(count, (unsigned) __popcll(mask));
+   base = (unsigned) __shfl((int) base, leader, 64);
+   return base + (unsigned) __popcll(mask & ((1ull << lane) - 1ull));
 }
 
 // ---------------------------------------------------------------- colour / BRDF (device)
@@ -377,8 +408,8 @@ __device__ __forceinline__ void remap_vectors(V3 normal, V3 tangent, V3 in_dir, 
 }
 
 // BRDFMaterial.getBRDFLuminocity materials/BRDFMaterial.java:53-92
-__device__ __noinline__ float brdf_luminocity(const float *__restrict__ dirs, const float *__restrict__ weights, int n_dirs,
-                                              int brdf_samples, V3 ray_dir, V3 point, V3 normal, V3 light)
+__device__ float brdf_luminocity(const float *__restrict__ dirs, const float *__restrict__ weights, int n_dirs, int brdf_samples,
+                                 V3 ray_dir, V3 point, V3 normal, V3 light)
 {
    float luminocity = 0.0f, weight = 0.0f;
    int ctr = 0;
@@ -430,7 +461,7 @@ __device__ __forceinline__ void phong_combine(const float color_in[3], const flo
    }
 }
 
-// java.util.Random restated (see DESIGN.md "sample jitter")
+// java.util.Random restated (DESIGN.md "sample jitter"): one stream per pixel
 __device__ __forceinline__ unsigned long long rng_init(unsigned long long seed, unsigned long long pixel)
 {
    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (pixel + 1ULL);
@@ -444,308 +475,450 @@ __device__ __forceinline__ float rng_next_float(unsigned long long &state)
    state = (state * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
    return (float) (int) (state >> 24) / (float) (1 << 24);
 }
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+// state after n further draws: the LCG's affine map composed n times (square-and-multiply)
+__device__ __forceinline__ unsigned long long rng_skip(unsigned long long state, unsigned n)
 {
-   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-   return v;
+   unsigned long long acc_mul = 1ULL, acc_add = 0ULL, cur_mul = 0x5DEECE66DULL, cur_add = 0xBULL;
+   while (n) {
+      if (n & 1u) {
+         acc_mul *= cur_mul;
+         acc_add = acc_add * cur_mul + cur_add;
+      }
+      cur_add = (cur_mul + 1ULL) * cur_add;
+      cur_mul *= cur_mul;
+      n >>= 1;
+   }
+   return (acc_mul * state + acc_add) & ((1ULL << 48) - 1);
 }
 
-enum { PH_PRIMARY = 0, PH_SECONDARY = 1, PH_SHADOW = 2 };
+__device__ __forceinline__ void store_ray(float *rays, unsigned idx, V3 o, V3 d, unsigned slot, int aux)
+{
+   float4 *q = (float4 *) rays + 2 * (size_t) idx;
+   q[0] = make_float4(o.x, o.y, o.z, __uint_as_float(slot));
+   q[1] = make_float4(d.x, d.y, d.z, __int_as_float(aux));
+}
+
+// pixel of (micro-tile, lane); false when it falls off the image
+__device__ __forceinline__ bool micro_pixel(const FrameArgs &p, int micro, int lane, int &px, int &py)
+{
+   const int k = micro / p.micro_per_tile;
+   const int within = micro % p.micro_per_tile;
+   const int tile = p.tile_rank + k * p.tile_world;
+   const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+   const int mpr = p.tile_size / 8;
+   px = tx * p.tile_size + (within % mpr) * 8 + (lane & 7);
+   py = ty * p.tile_size + (within / mpr) * 8 + (lane >> 3);
+   return (px < p.width) && (py < p.height);
+}
+
+__device__ __forceinline__ void write_miss_outputs(const FrameArgs &p, long long pix)
+{
+   if (p.hit_id) p.hit_id[pix] = -1;
+   if (p.hit_obj) p.hit_obj[pix] = -1;
+   if (p.hit_w) p.hit_w[pix] = 0.0f;
+}
 
 }   // namespace
 
-// ---------------------------------------------------------------- frame kernel
-//
-// One lane owns one pixel and walks its samples in order (RTStatics.computeColorAverage sums in
-// sample order).  Each trip round the outer loop traces ONE ray for every live lane, whatever kind
-// (primary, mirror bounce, shadow), so all ray kinds share one traversal loop and a lane on its
-// shadow ray runs beside a lane on its next primary ray.
-template <bool STATS>
-__global__ __launch_bounds__(BLOCK_THREADS) void render_kernel(const RenderParams p)
+// ---------------------------------------------------------------- generate
+// One wave = one 8x8 pixel group at one sample index j; sample slot = (group * ms + j) * 64 + lane.
+__global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs p)
 {
-   __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
-   const int tid = threadIdx.x;
-   const int lane = tid & 63;
-   int *stack = s_stack + tid;
-
-   const long long micro = (long long) blockIdx.x * (BLOCK_THREADS / 64) + (tid >> 6);
-   bool active = micro < (long long) p.n_micro;
-   int px = 0, py = 0;
-   if (active) {
-      const int k = (int) (micro / p.micro_per_tile);
-      const int within = (int) (micro % p.micro_per_tile);
-      const int tile = p.tile_rank + k * p.tile_world;
-      const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-      const int mpr = p.tile_size / 8;
-      px = tx * p.tile_size + (within % mpr) * 8 + (lane & 7);
-      py = ty * p.tile_size + (within / mpr) * 8 + (lane >> 3);
-      active = (px < p.width) && (py < p.height);
-   }
+   const int lane = threadIdx.x & 63;
+   const long long wave = (long long) blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6);
+   const int ms = p.multi_samples;
+   const long long n_waves = (long long) (p.micro_end - p.micro_begin) * ms;
+   if (wave >= n_waves) return;
+   const int local_micro = (int) (wave / ms);
+   const int j = (int) (wave % ms);
+   const unsigned slot = (unsigned) (wave * 64 + lane);
+   int px, py;
+   const bool active = micro_pixel(p, p.micro_begin + local_micro, lane, px, py);
    const long long pix = (long long) py * p.width + px;
 
-   const Consts k = { p.epsilon, p.near_plane, p.far_plane };
-   const V3 cam_o = mk3(p.origin[0], p.origin[1], p.origin[2]);
-   const V3 light = mk3(p.light_origin[0], p.light_origin[1], p.light_origin[2]);
-   // RenderThread.java:39-40
+   // RenderThread.java:39-47
    const float x0 = (float) px * p.x_inc + p.x_min;
    const float y0 = (float) py * p.y_inc + p.y_min;
-
-   unsigned long long rng = rng_init(p.rng_seed, (unsigned long long) pix);
-   Counters ctr = { 0u, 0u };
-   unsigned n_primary = 0, n_shadow = 0, n_secondary = 0, n_hits = 0;
-
-   int j = 0, phase = PH_PRIMARY, bounces = 0;
-   float ar = 0.0f, ag = 0.0f, ab = 0.0f;
-   V3 P0 = mk3(0, 0, 0), N0 = P0, D0 = P0;   // primary hit (for Phong)
-   V3 Pc = P0, Nc = P0, Dc = P0;             // hit whose material is being evaluated
-   int obj0 = 0, objc = 0;
-   float mat[3] = { 0.0f, 0.0f, 0.0f };
-
-   for (;;) {
-      if (!__any(active)) break;
-
-      // ---- next ray of this lane
-      V3 o = cam_o, d = mk3(0.0f, 0.0f, -1.0f);
-      int mirror = -1;
-      const bool shadow_mode = (phase == PH_SHADOW);
-      if (active) {
-         if (phase == PH_PRIMARY) {
-            float vx = x0, vy = y0;
-            if (j != 0) {   // RenderThread.java:43-44
-               vx = x0 + (rng_next_float(rng) * 2.0f - 1.0f) * p.x_inc / 2.0f;
-               vy = y0 + (rng_next_float(rng) * 2.0f - 1.0f) * p.y_inc / 2.0f;
-            }
-            const float vz = -p.near_plane_cam;
-            V3 t = mk3(p.rot[0] * vx + p.rot[1] * vy + p.rot[2] * vz, p.rot[3] * vx + p.rot[4] * vy + p.rot[5] * vz,
-                       p.rot[6] * vx + p.rot[7] * vy + p.rot[8] * vz);
-            d = normalize3(normalize3(t));   // RenderThread.java:47, then Ray ctor (Ray.java:12)
-            o = cam_o;
-            n_primary++;
-         } else if (phase == PH_SECONDARY) {
-            // ReflectionMaterial.java:16-17, Camera.java:196-200
-            o = add3(Pc, scale3(Nc, k.eps));
-            d = normalize3(reflect3(Nc, Dc));
-            mirror = objc;
-            n_secondary++;
-         } else {
-            // RTStatics.shadowIntersects RTStatics.java:618-622
-            d = normalize3(normalize3(sub3(light, P0)));
-            o = add3(P0, scale3(N0, k.eps));
-            n_shadow++;
-         }
-      }
-      Ray r;
-      make_ray(r, o, d, p.scene_abs_max);
-
-      // ---- objects, in scene order
-      ObjHit best;
-      best.face = -1;
-      best.key = 0;
-      best.w = 0.0f;
-      best.px = best.py = best.pz = best.u = best.v = 0.0f;
-      int best_obj = -1;
-      bool occluded = false;
-      for (int i = 0; i < p.n_objs; i++) {
-         const DevObject &ob = p.objs[i];
-         const bool want = active && (i != mirror) && !(shadow_mode && occluded);
-         const float lim2_in = (!shadow_mode && best_obj >= 0) ? prune_limit2(r, best.w) : __builtin_inff();
-         ObjHit h;
-         traverse_object<STATS>(ob, r, k, want, lim2_in, h, stack, ctr);
-         if (want && h.face >= 0) {
-            if (shadow_mode) {
-               if (h.w > k.eps) {   // RTStatics.java:628-633
-                  const float light_distance = distance3(mk3(h.px, h.py, h.pz), light);
-                  if (h.w < light_distance + k.eps) occluded = true;
-               }
-            } else if ((h.w > k.eps) && (best_obj < 0 || h.w < best.w)) {   // Camera.java:208
-               best = h;
-               best_obj = i;
-            }
-         }
-      }
-
-      // ---- consume the result
-      if (active) {
-         bool to_material = false, to_light = false, to_accum = false;
-         float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-         if (phase == PH_PRIMARY) {
-            if (best_obj < 0) {
-               cr = p.light_ambient[0];
-               cg = p.light_ambient[1];
-               cb = p.light_ambient[2];
-               to_accum = true;
-               if (j == 0) {
-                  if (p.hit_id) p.hit_id[pix] = -1;
-                  if (p.hit_obj) p.hit_obj[pix] = -1;
-                  if (p.hit_w) p.hit_w[pix] = 0.0f;
-               }
-            } else {
-               n_hits++;
-               P0 = mk3(best.px, best.py, best.pz);
-               N0 = hit_normal(p.objs, best_obj, best);
-               D0 = d;
-               obj0 = best_obj;
-               Pc = P0;
-               Nc = N0;
-               Dc = D0;
-               objc = obj0;
-               bounces = 0;
-               to_material = true;
-               if (j == 0) {
-                  if (p.hit_id) p.hit_id[pix] = best.face;
-                  if (p.hit_obj) p.hit_obj[pix] = best_obj;
-                  if (p.hit_w) p.hit_w[pix] = best.w;
-               }
-            }
-         } else if (phase == PH_SECONDARY) {
-            if (best_obj < 0) {   // ReflectionMaterial.java:19-20
-               mat[0] = p.light_ambient[0];
-               mat[1] = p.light_ambient[1];
-               mat[2] = p.light_ambient[2];
-               to_light = true;
-            } else {
-               Pc = mk3(best.px, best.py, best.pz);
-               Nc = hit_normal(p.objs, best_obj, best);
-               Dc = d;
-               objc = best_obj;
-               bounces++;
-               to_material = true;
-            }
-         } else {
-            const DevMaterial &m0 = p.objs[obj0].mat;
-            float out[3];
-            phong_combine(mat, m0.diffuse, m0.specular, m0.shininess, p.light_emission, p.light_ambient, light, P0, N0, D0, occluded,
-                          out);
-            cr = out[0];
-            cg = out[1];
-            cb = out[2];
-            to_accum = true;
-         }
-
-         if (to_material) {
-            const DevMaterial &m = p.objs[objc].mat;
-            if (m.kind == 2u /* reflection */ && bounces < p.max_mirror_bounces) {
-               phase = PH_SECONDARY;
-            } else if (m.kind == 1u /* BRDF */) {
-               // BRDFMaterial.getMaterialColor materials/BRDFMaterial.java:158-167
-               const float lum = brdf_luminocity(p.brdf_dirs, p.brdf_weights + (size_t) m.brdf_id * (size_t) p.n_dirs, p.n_dirs,
-                                                 p.brdf_samples, Dc, Pc, Nc, light);
-               float hsv[3];
-               rgb_to_hsv(m.diffuse, hsv);
-               hsv[2] = lum;
-               hsv_to_rgb(hsv, mat);
-               to_light = true;
-            } else {
-               mat[0] = m.diffuse[0];
-               mat[1] = m.diffuse[1];
-               mat[2] = m.diffuse[2];
-               to_light = true;
-            }
-         }
-         if (to_light) {
-            if (p.lighting_model == 1) {
-               phase = PH_SHADOW;
-            } else {
-               cr = mat[0];
-               cg = mat[1];
-               cb = mat[2];
-               to_accum = true;
-            }
-         }
-         if (to_accum) {
-            ar += cr;
-            ag += cg;
-            ab += cb;
-            j++;
-            phase = PH_PRIMARY;
-            if (j >= p.multi_samples) {
-               // RTStatics.computeColorAverage + Camera.setPixel
-               float fr = ar / (float) p.multi_samples, fg = ag / (float) p.multi_samples, fb = ab / (float) p.multi_samples;
-               if (fr != fr || fg != fg || fb != fb) fr = fg = fb = 0.0f;
-               if (p.rgb) {
-                  p.rgb[3 * pix + 0] = fr;
-                  p.rgb[3 * pix + 1] = fg;
-                  p.rgb[3 * pix + 2] = fb;
-               }
-               if (p.argb8) {
-                  const float br = jminf(1.0f, jmaxf(0.0f, fr)), bg = jminf(1.0f, jmaxf(0.0f, fg)), bb = jminf(1.0f, jmaxf(0.0f, fb));
-                  const unsigned ir = (unsigned) (int) ((double) (br * 255.0f) + 0.5);
-                  const unsigned ig = (unsigned) (int) ((double) (bg * 255.0f) + 0.5);
-                  const unsigned ib = (unsigned) (int) ((double) (bb * 255.0f) + 0.5);
-                  p.argb8[pix] = 0xFF000000u | ((ir & 255u) << 16) | ((ig & 255u) << 8) | (ib & 255u);
-               }
-               active = false;
-            }
-         }
-      }
+   float vx = x0, vy = y0;
+   if (j != 0) {
+      unsigned long long rng = rng_skip(rng_init(p.rng_seed, (unsigned long long) pix), 2u * (unsigned) (j - 1));
+      vx = x0 + (rng_next_float(rng) * 2.0f - 1.0f) * p.x_inc / 2.0f;
+      vy = y0 + (rng_next_float(rng) * 2.0f - 1.0f) * p.y_inc / 2.0f;
    }
+   const float vz = -p.near_plane_cam;
+   const V3 t = mk3(p.rot[0] * vx + p.rot[1] * vy + p.rot[2] * vz, p.rot[3] * vx + p.rot[4] * vy + p.rot[5] * vz,
+                    p.rot[6] * vx + p.rot[7] * vy + p.rot[8] * vz);
+   const V3 d = normalize3(normalize3(t));   // RenderThread.java:47, then the Ray ctor (Ray.java:12)
+   const V3 o = mk3(p.origin[0], p.origin[1], p.origin[2]);
+   Ray r;
+   make_ray(r, o, d, p.sc.scene_abs_max);
 
-   if (STATS && p.stats) {
-      const unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_secondary);
-      const unsigned long long s3 = wave_sum(ctr.box), s4 = wave_sum(ctr.tri), s5 = wave_sum(n_hits);
-      if (lane == 0) {
-         atomicAdd(&p.stats[0], s0);
-         atomicAdd(&p.stats[1], s1);
-         atomicAdd(&p.stats[2], s2);
-         atomicAdd(&p.stats[3], s3);
-         atomicAdd(&p.stats[4], s4);
-         atomicAdd(&p.stats[5], s5);
-      }
+   // Camera.java:205: object.intersects(ray) for each object; a ray that enters no root box is a miss
+   bool any_root = false;
+   for (int i = 0; i < p.sc.n_objs; i++) {
+      const DevObject &ob = p.sc.objs[i];
+      float te;
+      any_root = any_root || slab_test(r, p.sc.near_plane, p.sc.far_plane, ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0],
+                                       ob.bmax[1], ob.bmax[2], te);
+   }
+   const bool push = active && any_root;
+   if (active && !any_root) {
+      ((float4 *) p.samples)[slot] = make_float4(p.light_ambient[0], p.light_ambient[1], p.light_ambient[2], 0.0f);
+      if (j == 0) write_miss_outputs(p, pix);
+   }
+   const unsigned idx = queue_push(p.counters + CNT_Q0, push);
+   if (push) store_ray(p.rays0, idx, o, d, slot, -1);
+   if (p.stats) {
+      add_stat(p.counters, ST_PRIMARY, active ? 1u : 0u);
+      add_stat(p.counters, ST_BOX, active ? (unsigned) p.sc.n_objs : 0u);
    }
 }
 
-// ---------------------------------------------------------------- ray-batch kernel
-// Camera.getClosestIntersection(null, origin, direction, null, 0) per ray.
-__global__ __launch_bounds__(BLOCK_THREADS) void trace_rays_kernel(const TraceParams p)
+// ---------------------------------------------------------------- trace (closest hit)
+// Camera.getClosestIntersection (Camera.java:193-215) for every ray of a queue.  aux of a ray is
+// the mirror object to skip (-1: none) in its low 16 bits.
+struct TraceArgs {
+   SceneArgs sc;
+   const float *rays;
+   float *hits;
+   int32_t *hit_obj;
+   uint32_t *counters;
+   int32_t count_index, cursor_index;
+   int32_t stats;
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const TraceArgs a)
 {
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
    int *stack = s_stack + threadIdx.x;
-   const unsigned long long i = (unsigned long long) blockIdx.x * BLOCK_THREADS + threadIdx.x;
-   const bool active = i < p.n;
-   const Consts k = { p.epsilon, p.near_plane, p.far_plane };
-   V3 o = mk3(0, 0, 0), d = mk3(0, 0, -1);
-   if (active) {
-      o = mk3(p.origins[3 * i], p.origins[3 * i + 1], p.origins[3 * i + 2]);
-      d = normalize3(mk3(p.dirs[3 * i], p.dirs[3 * i + 1], p.dirs[3 * i + 2]));   // Ray ctor
-   }
-   Ray r;
-   make_ray(r, o, d, p.scene_abs_max);
-   Counters ctr = { 0u, 0u };
-   ObjHit best;
-   best.face = -1;
-   best.key = 0;
-   best.w = 0.0f;
-   best.px = best.py = best.pz = best.u = best.v = 0.0f;
-   int best_obj = -1;
-   for (int j = 0; j < p.n_objs; j++) {
-      const float lim2_in = (best_obj >= 0) ? prune_limit2(r, best.w) : __builtin_inff();
-      ObjHit h;
-      traverse_object<false>(p.objs[j], r, k, active, lim2_in, h, stack, ctr);
-      if (active && h.face >= 0 && (h.w > k.eps) && (best_obj < 0 || h.w < best.w)) {
-         best = h;
-         best_obj = j;
+   const int lane = threadIdx.x & 63;
+   const unsigned count = a.counters[a.count_index];
+   unsigned n_box = 0, n_tri = 0, n_hit = 0;
+   unsigned base;
+   while (next_batch(a.counters + a.cursor_index, count, base)) {
+      const unsigned i = base + (unsigned) lane;
+      const bool active = i < count;
+      V3 o = mk3(0, 0, 0), d = mk3(0, 0, -1);
+      int mirror = -1;
+      if (active) {
+         const float4 *q = (const float4 *) a.rays + 2 * (size_t) i;
+         const float4 r0 = q[0], r1 = q[1];
+         o = mk3(r0.x, r0.y, r0.z);
+         d = mk3(r1.x, r1.y, r1.z);
+         mirror = (int) (short) (__float_as_int(r1.w) & 0xffff);
+      }
+      Ray r;
+      make_ray(r, o, d, a.sc.scene_abs_max);
+      float best_w = 0.0f;
+      int best_slot = -1, best_obj = -1;
+      for (int k = 0; k < a.sc.n_objs; k++) {
+         const DevObject &ob = a.sc.objs[k];
+         const bool want = active && (k != mirror);
+         const float lim2_in = best_obj >= 0 ? prune_limit2(r, best_w) : __builtin_inff();
+         Best h;
+         traverse_object<STATS, false>(ob, r, a.sc, want, lim2_in, h, stack, n_box, n_tri);
+         if (want && h.slot >= 0 && (h.w > a.sc.epsilon) && (best_obj < 0 || h.w < best_w)) {   // Camera.java:208
+            best_w = h.w;
+            best_slot = h.slot;
+            best_obj = k;
+         }
+      }
+      if (active) {
+         float4 h0 = make_float4(0, 0, 0, 0), h1 = make_float4(0, 0, 0, __int_as_float(-1));
+         if (best_obj >= 0) {
+            // the winner's point, barycentrics and normal, recomputed once (same arithmetic => same bits)
+            const DevObject *ob = a.sc.objs + best_obj;
+            const float4 *t = (const float4 *) ob->tris + 3 * (size_t) best_slot;
+            const float4 A = t[0], B = t[1], C = t[2];
+            float u = 0, v = 0, dist = 0;
+            V3 P = mk3(0, 0, 0);
+            (void) tri_test(A, B, C, r, a.sc.epsilon, u, v, P, dist);
+            const int face = __float_as_int(A.w);
+            const float4 *fn = (const float4 *) ob->fnrm + 3 * (size_t) face;
+            const float4 n0 = fn[0], n1 = fn[1], n2 = fn[2];
+            const float wb = 1.0f - u - v;   // Triangle.java:126-129, not renormalised
+            h0 = make_float4(P.x, P.y, P.z, dist);
+            h1 = make_float4(wb * n0.x + u * n1.x + v * n2.x, wb * n0.y + u * n1.y + v * n2.y, wb * n0.z + u * n1.z + v * n2.z,
+                             __int_as_float(face));
+            n_hit++;
+         }
+         float4 *hq = (float4 *) a.hits + 2 * (size_t) i;
+         hq[0] = h0;
+         hq[1] = h1;
+         a.hit_obj[i] = best_obj;
       }
    }
-   if (!active) return;
-   V3 n = mk3(0, 0, 0);
-   if (best_obj >= 0 && p.hit_normal) n = hit_normal(p.objs, best_obj, best);
-   if (p.hit_id) p.hit_id[i] = best_obj >= 0 ? best.face : -1;
-   if (p.hit_obj) p.hit_obj[i] = best_obj;
-   if (p.hit_w) p.hit_w[i] = best_obj >= 0 ? best.w : 0.0f;
-   if (p.hit_point) {
-      p.hit_point[3 * i] = best.px;
-      p.hit_point[3 * i + 1] = best.py;
-      p.hit_point[3 * i + 2] = best.pz;
-   }
-   if (p.hit_normal) {
-      p.hit_normal[3 * i] = n.x;
-      p.hit_normal[3 * i + 1] = n.y;
-      p.hit_normal[3 * i + 2] = n.z;
+   if (STATS) {
+      add_stat(a.counters, ST_BOX, n_box);
+      add_stat(a.counters, ST_TRI, n_tri);
+      add_stat(a.counters, ST_HITS, a.stats == 2 ? n_hit : 0u);
    }
 }
 
-// device arithmetic probe used by the GPU tests: the three primitives parity rests on
+// ---------------------------------------------------------------- shade hits
+// LEVEL 0: primary queue (Q0).  LEVEL 1: a secondary (mirror bounce) queue; aux >> 16 = bounces so
+// far, slot = index of the path's primary queue entry.
+template <int LEVEL>
+__global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p, const float *rays, const float *hits,
+                                                              const int32_t *hit_obj, int count_index, float *rays_next,
+                                                              int next_count_index)
+{
+   const unsigned count = p.counters[count_index];
+   unsigned n_sec = 0;
+   for (unsigned base = blockIdx.x * BLOCK_THREADS; base < count; base += gridDim.x * BLOCK_THREADS) {
+   const unsigned i = base + threadIdx.x;
+   const bool active = i < count;
+   bool push_shadow = false, push_sec = false;
+   unsigned path = 0;
+   V3 sec_o = mk3(0, 0, 0), sec_d = mk3(0, 0, -1);
+   int sec_aux = 0;
+   if (active) {
+      const float4 *q = (const float4 *) rays + 2 * (size_t) i;
+      const float4 r0 = q[0], r1 = q[1];
+      const float4 *hq = (const float4 *) hits + 2 * (size_t) i;
+      const float4 h0 = hq[0], h1 = hq[1];
+      const int obj = hit_obj[i];
+      const unsigned slot_or_path = __float_as_uint(r0.w);
+      const int aux = __float_as_int(r1.w);
+      const int bounces = LEVEL == 0 ? 0 : (aux >> 16);
+      path = LEVEL == 0 ? i : slot_or_path;
+      // the sample slot and pixel of this path
+      const unsigned slot = LEVEL == 0 ? slot_or_path : __float_as_uint(((const float4 *) p.rays0)[2 * (size_t) path].w);
+      float mat[3];
+      bool have_mat = false;
+      if (obj < 0) {
+         if (LEVEL == 0) {
+            // RenderThread.java:53-55
+            ((float4 *) p.samples)[slot] = make_float4(p.light_ambient[0], p.light_ambient[1], p.light_ambient[2], 0.0f);
+         } else {
+            // ReflectionMaterial.java:19-20
+            mat[0] = p.light_ambient[0];
+            mat[1] = p.light_ambient[1];
+            mat[2] = p.light_ambient[2];
+            have_mat = true;
+         }
+      } else {
+         const DevMaterial &m = p.sc.objs[obj].mat;
+         const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), D = mk3(r1.x, r1.y, r1.z);
+         if (m.kind == 2u && bounces < p.max_mirror_bounces) {
+            // ReflectionMaterial.java:16-17 + Camera.java:196-200 (offset origin, Ray ctor normalises again)
+            sec_o = add3(P, scale3(N, p.sc.epsilon));
+            sec_d = normalize3(reflect3(N, D));
+            sec_aux = (obj & 0xffff) | ((bounces + 1) << 16);
+            push_sec = true;
+            n_sec++;
+         } else if (m.kind == 1u) {
+            // BRDFMaterial.getMaterialColor materials/BRDFMaterial.java:158-167
+            const V3 light = mk3(p.light_origin[0], p.light_origin[1], p.light_origin[2]);
+            const float lum = brdf_luminocity(p.brdf_dirs, p.brdf_weights + (size_t) m.brdf_id * (size_t) p.n_dirs, p.n_dirs,
+                                              p.brdf_samples, D, P, N, light);
+            float hsv[3];
+            rgb_to_hsv(m.diffuse, hsv);
+            hsv[2] = lum;
+            hsv_to_rgb(hsv, mat);
+            have_mat = true;
+         } else {
+            mat[0] = m.diffuse[0];
+            mat[1] = m.diffuse[1];
+            mat[2] = m.diffuse[2];
+            have_mat = true;
+         }
+      }
+      if (LEVEL == 0) {
+         const unsigned wave = slot >> 6;
+         const int j = (int) (wave % (unsigned) p.multi_samples);
+         if (j == 0 && (p.hit_id || p.hit_obj || p.hit_w)) {
+            int px, py;
+            (void) micro_pixel(p, p.micro_begin + (int) (wave / (unsigned) p.multi_samples), (int) (slot & 63u), px, py);
+            const long long pix = (long long) py * p.width + px;
+            if (obj < 0) {
+               write_miss_outputs(p, pix);
+            } else {
+               if (p.hit_id) p.hit_id[pix] = __float_as_int(h1.w);
+               if (p.hit_obj) p.hit_obj[pix] = obj;
+               if (p.hit_w) p.hit_w[pix] = h0.w;
+            }
+         }
+      }
+      if (have_mat) {
+         if (p.lighting_model == 1) {
+            ((float4 *) p.mat0)[path] = make_float4(mat[0], mat[1], mat[2], 0.0f);
+            push_shadow = true;
+         } else {
+            ((float4 *) p.samples)[slot] = make_float4(mat[0], mat[1], mat[2], 0.0f);   // LightingModel.java:13-15
+         }
+      }
+   }
+   const unsigned si = queue_push(p.counters + CNT_SHADOW, push_shadow);
+   if (push_shadow) p.shadow[si] = path;
+   if (rays_next) {
+      const unsigned qi = queue_push(p.counters + next_count_index, push_sec);
+      if (push_sec) store_ray(rays_next, qi, sec_o, sec_d, path, sec_aux);
+   }
+   }
+   if (p.stats) add_stat(p.counters, ST_SECONDARY, n_sec);
+}
+
+// ---------------------------------------------------------------- shadow rays
+// RTStatics.shadowIntersects (RTStatics.java:617-639) for every path in the shadow list; the flag
+// goes into mat0[path].w.
+struct ShadowArgs {
+   SceneArgs sc;
+   const float *hits0;
+   float *mat0;
+   const uint32_t *shadow;
+   uint32_t *counters;
+   int32_t cursor_index;
+   float light[3];
+   int32_t stats;
+};
+
+template <bool STATS, bool ANY>
+__global__ __launch_bounds__(BLOCK_THREADS) void shadow_kernel(const ShadowArgs a)
+{
+   __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
+   int *stack = s_stack + threadIdx.x;
+   const int lane = threadIdx.x & 63;
+   const unsigned count = a.counters[CNT_SHADOW];
+   const V3 light = mk3(a.light[0], a.light[1], a.light[2]);
+   unsigned n_box = 0, n_tri = 0, n_ray = 0;
+   unsigned base;
+   while (next_batch(a.counters + a.cursor_index, count, base)) {
+      const unsigned i = base + (unsigned) lane;
+      const bool active = i < count;
+      V3 o = mk3(0, 0, 0), d = mk3(0, 0, -1);
+      unsigned path = 0;
+      if (active) {
+         path = a.shadow[i];
+         const float4 *hq = (const float4 *) a.hits0 + 2 * (size_t) path;
+         const float4 h0 = hq[0], h1 = hq[1];
+         const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z);
+         d = normalize3(normalize3(sub3(light, P)));   // RTStatics.java:619-620, then the Ray ctor
+         o = add3(P, scale3(N, a.sc.epsilon));         // RTStatics.offsetPosition
+         n_ray++;
+      }
+      Ray r;
+      make_ray(r, o, d, a.sc.scene_abs_max);
+      bool occluded = false;
+      for (int k = 0; k < a.sc.n_objs; k++) {
+         const DevObject &ob = a.sc.objs[k];
+         const bool want = active && !occluded;
+         Best h;
+         traverse_object<STATS, ANY>(ob, r, a.sc, want, __builtin_inff(), h, stack, n_box, n_tri);
+         if (want && h.slot >= 0) {
+            if (ANY) {
+               occluded = true;   // host-proven equivalent (api.cpp: shadow_any_hit)
+            } else if (h.w > a.sc.epsilon) {   // RTStatics.java:628-633
+               const float4 *t = (const float4 *) ob.tris + 3 * (size_t) h.slot;
+               float u, v, dist;
+               V3 P;
+               (void) tri_test(t[0], t[1], t[2], r, a.sc.epsilon, u, v, P, dist);
+               const float light_distance = distance3(P, light);
+               if (h.w < light_distance + a.sc.epsilon) occluded = true;
+            }
+         }
+      }
+      if (active) a.mat0[4 * (size_t) path + 3] = occluded ? 1.0f : 0.0f;
+   }
+   if (STATS) {
+      add_stat(a.counters, ST_SHADOW, n_ray);
+      add_stat(a.counters, ST_BOX, n_box);
+      add_stat(a.counters, ST_TRI, n_tri);
+   }
+}
+
+// ---------------------------------------------------------------- Phong combine
+__global__ __launch_bounds__(BLOCK_THREADS) void phong_kernel(const FrameArgs p)
+{
+   const unsigned count = p.counters[CNT_SHADOW];
+   for (unsigned i = blockIdx.x * BLOCK_THREADS + threadIdx.x; i < count; i += gridDim.x * BLOCK_THREADS) {
+   const unsigned path = p.shadow[i];
+   const float4 *q = (const float4 *) p.rays0 + 2 * (size_t) path;
+   const float4 r0 = q[0], r1 = q[1];
+   const float4 *hq = (const float4 *) p.hits0 + 2 * (size_t) path;
+   const float4 h0 = hq[0], h1 = hq[1];
+   const float4 m4 = ((const float4 *) p.mat0)[path];
+   const int obj = p.hit_obj0[path];
+   const DevMaterial &m0 = p.sc.objs[obj].mat;
+   const float mat[3] = { m4.x, m4.y, m4.z };
+   float out[3];
+   phong_combine(mat, m0.diffuse, m0.specular, m0.shininess, p.light_emission, p.light_ambient,
+                 mk3(p.light_origin[0], p.light_origin[1], p.light_origin[2]), mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z),
+                 mk3(r1.x, r1.y, r1.z), m4.w != 0.0f, out);
+   ((float4 *) p.samples)[__float_as_uint(r0.w)] = make_float4(out[0], out[1], out[2], 0.0f);
+   }
+}
+
+// ---------------------------------------------------------------- resolve
+// RTStatics.computeColorAverage (sample order) + Camera.setPixel (NaN scrub, 8-bit pack)
+__global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const FrameArgs p)
+{
+   const int lane = threadIdx.x & 63;
+   const long long local_micro = (long long) blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6);
+   if (local_micro >= (long long) (p.micro_end - p.micro_begin)) return;
+   int px, py;
+   if (!micro_pixel(p, p.micro_begin + (int) local_micro, lane, px, py)) return;
+   const long long pix = (long long) py * p.width + px;
+   const int ms = p.multi_samples;
+   const float4 *s = (const float4 *) p.samples + (size_t) local_micro * (size_t) ms * 64 + lane;
+   float r = 0.0f, g = 0.0f, b = 0.0f;
+   for (int j = 0; j < ms; j++) {
+      const float4 c = s[(size_t) j * 64];
+      r += c.x;
+      g += c.y;
+      b += c.z;
+   }
+   float fr = r / (float) ms, fg = g / (float) ms, fb = b / (float) ms;
+   if (fr != fr || fg != fg || fb != fb) fr = fg = fb = 0.0f;
+   if (p.rgb) {
+      p.rgb[3 * pix + 0] = fr;
+      p.rgb[3 * pix + 1] = fg;
+      p.rgb[3 * pix + 2] = fb;
+   }
+   if (p.argb8) {
+      const float br = jminf(1.0f, jmaxf(0.0f, fr)), bg = jminf(1.0f, jmaxf(0.0f, fg)), bb = jminf(1.0f, jmaxf(0.0f, fb));
+      const unsigned ir = (unsigned) (int) ((double) (br * 255.0f) + 0.5);
+      const unsigned ig = (unsigned) (int) ((double) (bg * 255.0f) + 0.5);
+      const unsigned ib = (unsigned) (int) ((double) (bb * 255.0f) + 0.5);
+      p.argb8[pix] = 0xFF000000u | ((ir & 255u) << 16) | ((ig & 255u) << 8) | (ib & 255u);
+   }
+}
+
+// ---------------------------------------------------------------- ray batches (mi355rt_trace_rays)
+__global__ void batch_pack_kernel(const TraceBatchArgs a)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= a.n) return;
+   const V3 o = mk3(a.origins[3 * (size_t) i], a.origins[3 * (size_t) i + 1], a.origins[3 * (size_t) i + 2]);
+   const V3 d = normalize3(mk3(a.dirs[3 * (size_t) i], a.dirs[3 * (size_t) i + 1], a.dirs[3 * (size_t) i + 2]));   // Ray ctor
+   store_ray(a.rays, i, o, d, i, -1);
+   if (i == 0) a.counters[CNT_Q0] = a.n;
+}
+
+__global__ void batch_unpack_kernel(const TraceBatchArgs a)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= a.n) return;
+   const float4 *hq = (const float4 *) a.hits + 2 * (size_t) i;
+   const float4 h0 = hq[0], h1 = hq[1];
+   const int obj = a.hit_obj[i];
+   if (a.out_id) a.out_id[i] = obj >= 0 ? __float_as_int(h1.w) : -1;
+   if (a.out_obj) a.out_obj[i] = obj;
+   if (a.out_w) a.out_w[i] = obj >= 0 ? h0.w : 0.0f;
+   if (a.out_point) {
+      a.out_point[3 * (size_t) i] = h0.x;
+      a.out_point[3 * (size_t) i + 1] = h0.y;
+      a.out_point[3 * (size_t) i + 2] = h0.z;
+   }
+   if (a.out_normal) {
+      a.out_normal[3 * (size_t) i] = h1.x;
+      a.out_normal[3 * (size_t) i + 1] = h1.y;
+      a.out_normal[3 * (size_t) i + 2] = h1.z;
+   }
+}
+
+// device arithmetic probe used by the GPU tests: the primitives parity rests on
 __global__ void arith_probe_kernel(unsigned long long n, const float *a, const float *b, float *out_div, float *out_sqrt,
                                    float *out_rnorm, float *out_pow)
 {
@@ -759,22 +932,117 @@ __global__ void arith_probe_kernel(unsigned long long n, const float *a, const f
 
 // ---------------------------------------------------------------- launchers
 
-hipError_t launch_render(const RenderParams &p, bool stats, hipStream_t stream)
+namespace {
+
+unsigned blocks_for(unsigned long long n) { return (unsigned) ((n + BLOCK_THREADS - 1) / BLOCK_THREADS); }
+
+// persistent grids: enough resident waves to fill the chip, never more than the work can use
+unsigned persistent_grid(int n_cus, unsigned long long max_items)
 {
-   if (p.n_micro <= 0) return hipSuccess;
-   const unsigned waves_per_block = BLOCK_THREADS / 64;
-   const unsigned grid = (unsigned) ((p.n_micro + waves_per_block - 1) / waves_per_block);
-   if (stats) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
-   else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p);
+   const unsigned long long want = (unsigned long long) n_cus * 6ull;   // 6 blocks of 4 waves per CU (LDS-limited)
+   const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
+   return (unsigned) (need < want ? (need ? need : 1ull) : want);
+}
+
+// grid-stride kernels (queue length known only on the device): a few blocks per CU at most
+unsigned bounded_grid(int n_cus, unsigned long long max_items)
+{
+   const unsigned long long want = (unsigned long long) n_cus * 8ull;
+   const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
+   return (unsigned) (need < want ? (need ? need : 1ull) : want);
+}
+
+}   // namespace
+
+hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
+                        int cursor_index, unsigned long long max_items, int n_cus, int stats, hipStream_t stream)
+{
+   TraceArgs a;
+   a.sc = sc;
+   a.rays = rays;
+   a.hits = hits;
+   a.hit_obj = hit_obj;
+   a.counters = counters;
+   a.count_index = count_index;
+   a.cursor_index = cursor_index;
+   a.stats = stats;
+   const unsigned grid = persistent_grid(n_cus, max_items);
+   if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
    return hipGetLastError();
 }
 
-hipError_t launch_trace_rays(const TraceParams &p, hipStream_t stream)
+hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
 {
-   if (p.n == 0) return hipSuccess;
-   const unsigned long long grid = (p.n + BLOCK_THREADS - 1) / BLOCK_THREADS;
-   if (grid > 0x7fffffffULL) return hipErrorInvalidValue;
-   hipLaunchKernelGGL(trace_rays_kernel, dim3((unsigned) grid), dim3(BLOCK_THREADS), 0, stream, p);
+   const unsigned long long waves = (unsigned long long) (p.micro_end - p.micro_begin) * (unsigned long long) p.multi_samples;
+   if (!waves) return hipSuccess;
+   hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(waves * 64)), dim3(BLOCK_THREADS), 0, stream, p);
+   return hipGetLastError();
+}
+
+hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const float *hits, const int32_t *hit_obj, int count_index,
+                        float *rays_next, int next_count_index, unsigned long long max_items, int n_cus, hipStream_t stream)
+{
+   if (!max_items) return hipSuccess;
+   const unsigned grid = bounded_grid(n_cus, max_items);
+   if (level == 0)
+      hipLaunchKernelGGL(shade_kernel<0>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
+                         next_count_index);
+   else
+      hipLaunchKernelGGL(shade_kernel<1>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
+                         next_count_index);
+   return hipGetLastError();
+}
+
+hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long long max_items, int n_cus, hipStream_t stream)
+{
+   ShadowArgs a;
+   a.sc = p.sc;
+   a.hits0 = p.hits0;
+   a.mat0 = p.mat0;
+   a.shadow = p.shadow;
+   a.counters = p.counters;
+   a.cursor_index = cursor_index;
+   a.light[0] = p.light_origin[0];
+   a.light[1] = p.light_origin[1];
+   a.light[2] = p.light_origin[2];
+   a.stats = p.stats;
+   const unsigned grid = persistent_grid(n_cus, max_items);
+   const dim3 g(grid), b(BLOCK_THREADS);
+   if (p.stats) {
+      if (p.shadow_any_hit) hipLaunchKernelGGL((shadow_kernel<true, true>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((shadow_kernel<true, false>), g, b, 0, stream, a);
+   } else {
+      if (p.shadow_any_hit) hipLaunchKernelGGL((shadow_kernel<false, true>), g, b, 0, stream, a);
+      else hipLaunchKernelGGL((shadow_kernel<false, false>), g, b, 0, stream, a);
+   }
+   return hipGetLastError();
+}
+
+hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream)
+{
+   if (!max_items) return hipSuccess;
+   hipLaunchKernelGGL(phong_kernel, dim3(bounded_grid(n_cus, max_items)), dim3(BLOCK_THREADS), 0, stream, p);
+   return hipGetLastError();
+}
+
+hipError_t launch_resolve(const FrameArgs &p, hipStream_t stream)
+{
+   const unsigned long long micro = (unsigned long long) (p.micro_end - p.micro_begin);
+   if (!micro) return hipSuccess;
+   hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(micro * 64)), dim3(BLOCK_THREADS), 0, stream, p);
+   return hipGetLastError();
+}
+
+hipError_t launch_batch_pack(const TraceBatchArgs &a, hipStream_t stream)
+{
+   hipLaunchKernelGGL(batch_pack_kernel, dim3(blocks_for(a.n)), dim3(BLOCK_THREADS), 0, stream, a);
+   return hipGetLastError();
+}
+
+hipError_t launch_batch_unpack(const TraceBatchArgs &a, hipStream_t stream)
+{
+   hipLaunchKernelGGL(batch_unpack_kernel, dim3(blocks_for(a.n)), dim3(BLOCK_THREADS), 0, stream, a);
    return hipGetLastError();
 }
 
