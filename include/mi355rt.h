@@ -176,6 +176,11 @@ void mi355rt_free(void *p);
 int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_div, float *out_sqrt, float *out_rnorm,
                         float *out_pow);
 
+/* Diagnostic: the 16 raw 64-bit counters of the most recent collect_stats render: [0..5] = mi355rt_stats,
+ * [6..11] = lane-trips / wave-trips of the walker's node and leaf loops, outer trips, refills.
+ * No counterpart in the reference. */
+int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[16]);
+
 const char *mi355rt_last_error(void);
 int mi355rt_abi_version(void);
 int mi355rt_device_count(void);

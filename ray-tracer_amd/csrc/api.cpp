@@ -67,7 +67,6 @@ struct HostObject {
    float shadow_distance;
    uint64_t n_nodes, n_leaves, n_slots;
    int32_t max_depth;
-   void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;
 };
 
 }   // namespace
@@ -91,6 +90,7 @@ struct mi355rt_scene {
    std::vector<HostObject> objects;
    std::vector<mi355rt_material> materials;
    DevObject *d_objs = nullptr;
+   void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;   // all objects, concatenated
    float *d_brdf_dirs = nullptr, *d_brdf_weights = nullptr;
    int32_t n_dirs = 0, n_materials = 0;
    float smin[3], smax[3];   // scene bounds (Scene.java:21-33)
@@ -101,6 +101,7 @@ struct mi355rt_scene {
    uint32_t *d_counters = nullptr;   // CNT_WORDS
    bool stats_valid = false;
    mi355rt_stats stats_accum {};
+   unsigned long long diag[16] = { 0 };
    FrameScratch scratch;
    // frame buffers of the host-buffer render entry point
    float *d_rgb = nullptr;
@@ -122,11 +123,9 @@ void free_scratch(FrameScratch &fs)
 void release_scene(mi355rt_scene *s)
 {
    if (!s) return;
-   for (HostObject &o : s->objects) {
-      if (o.d_nodes) (void) hipFree(o.d_nodes);
-      if (o.d_tris) (void) hipFree(o.d_tris);
-      if (o.d_fnrm) (void) hipFree(o.d_fnrm);
-   }
+   if (s->d_nodes) (void) hipFree(s->d_nodes);
+   if (s->d_tris) (void) hipFree(s->d_tris);
+   if (s->d_fnrm) (void) hipFree(s->d_fnrm);
    if (s->d_objs) (void) hipFree(s->d_objs);
    if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
    if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
@@ -228,6 +227,9 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    if ((size_t) st->multi_samples * 64 > PASS_SLOTS) return fail(MI355RT_E_LIMIT, "multi_samples too large");
    std::memset(&p, 0, sizeof(p));
    p.sc.objs = s->d_objs;
+   p.sc.nodes = s->d_nodes;
+   p.sc.tris = s->d_tris;
+   p.sc.fnrm = s->d_fnrm;
    p.sc.n_objs = (int32_t) s->objects.size();
    p.sc.epsilon = st->epsilon;
    p.sc.near_plane = st->near_plane;
@@ -312,8 +314,9 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t str
       p.micro_end = (int32_t) m1;
       HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
       HIP_TRY(launch_generate(p, stream));
-      int cursor = CNT_CURSOR0;
-      HIP_TRY(launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cursor++, slots, s->n_cus, p.stats ? 2 : 0, stream));
+      int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
+      auto next_cursor = [&]() -> int { return CNT_CURSOR0 + 8 * (cursor_set++); };
+      HIP_TRY(launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, next_cursor(), slots, s->n_cus, p.stats ? 2 : 0, stream));
       HIP_TRY(launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream));
       if (s->has_mirror) {
          // mirror bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
@@ -324,25 +327,26 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t str
             HIP_TRY(hipStreamSynchronize(stream));
             if (n_sec == 0) break;
             const int cur_cnt = cur == 0 ? CNT_SEC_A : CNT_SEC_B, nxt_cnt = cur == 0 ? CNT_SEC_B : CNT_SEC_A;
-            if (cursor >= CNT_STATS) cursor = CNT_CURSOR0 + 2;
-            HIP_TRY(hipMemsetAsync(p.counters + cursor, 0, sizeof(uint32_t), stream));
+            if (cursor_set >= CNT_CURSOR_SETS - 1) cursor_set = 1;   // keep the last set for the shadow launch
+            const int cw = next_cursor();
+            HIP_TRY(hipMemsetAsync(p.counters + cw, 0, 8 * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(p.counters + nxt_cnt, 0, sizeof(uint32_t), stream));
-            HIP_TRY(launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cursor++, n_sec, s->n_cus, p.stats ? 1 : 0, stream));
+            HIP_TRY(launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, n_sec, s->n_cus, p.stats ? 1 : 0, stream));
             HIP_TRY(launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream));
             cur ^= 1;
          }
       }
       if (p.lighting_model == MI355RT_LIGHTING_PHONG) {
-         if (cursor >= CNT_STATS) cursor = CNT_CURSOR0 + 2;
-         HIP_TRY(hipMemsetAsync(p.counters + cursor, 0, sizeof(uint32_t), stream));
-         HIP_TRY(launch_shadow(p, cursor++, slots, s->n_cus, stream));
+         const int cw = CNT_CURSOR0 + 8 * (CNT_CURSOR_SETS - 1);
+         HIP_TRY(launch_shadow(p, cw, slots, s->n_cus, stream));
          HIP_TRY(launch_phong(p, slots, s->n_cus, stream));
       }
       HIP_TRY(launch_resolve(p, stream));
       if (p.stats) {
-         unsigned long long h[6];
+         unsigned long long h[16];
          HIP_TRY(hipMemcpyAsync(h, p.counters + CNT_STATS, sizeof(h), hipMemcpyDeviceToHost, stream));
          HIP_TRY(hipStreamSynchronize(stream));
+         for (int q = 0; q < 16; q++) s->diag[q] = (m0 == 0 ? 0ull : s->diag[q]) + h[q];
          s->stats_accum.primary_rays += h[0];
          s->stats_accum.shadow_rays += h[1];
          s->stats_accum.secondary_rays += h[2];
@@ -402,6 +406,10 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
    }
    std::vector<DevObject> dev_objs(n_meshes ? n_meshes : 1);
    std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
+   // all objects share one node array, one slot array and one normal array (links absolute)
+   std::vector<NodeRec> all_nodes;
+   std::vector<float> all_tris, all_fnrm;
+   size_t slot_total = 0, face_total = 0;
 
    try {
       for (uint32_t i = 0; i < n_meshes; i++) {
@@ -412,11 +420,22 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
             release_scene(s);
             return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
          }
-         // leaf slots: 3 x float4 per (leaf, face)
-         std::vector<float> tris(12 * bo_out.slot_face.size());
+         const size_t node_base = all_nodes.size(), slot_base = slot_total, face_base = face_total;
+         if (node_base + bo_out.nodes.size() > (size_t) 0x7ffffff0 || slot_base + bo_out.slot_face.size() > (size_t) 0x7ffffff0 ||
+             face_base + md.n_faces > (size_t) 0x7ffffff0) {
+            release_scene(s);
+            return fail(MI355RT_E_LIMIT, "scene exceeds 2^31 nodes, leaf slots or faces");
+         }
+         for (NodeRec rec : bo_out.nodes) {
+            if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? slot_base : node_base);
+            if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? slot_base : node_base);
+            all_nodes.push_back(rec);
+         }
+         // leaf slots: 3 x float4 per (leaf, face): { v0, faceId } { v1, faces left in the leaf } { v2, 0 }
+         all_tris.resize(12 * (slot_base + bo_out.slot_face.size()), 0.0f);
          for (size_t sidx = 0; sidx < bo_out.slot_face.size(); sidx++) {
             const int32_t f = bo_out.slot_face[sidx];
-            float *dst = tris.data() + 12 * sidx;
+            float *dst = all_tris.data() + 12 * (slot_base + sidx);
             for (int kx = 0; kx < 3; kx++) {
                const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
                dst[4 * kx + 0] = v[0];
@@ -425,18 +444,22 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
                dst[4 * kx + 3] = 0.0f;
             }
             std::memcpy(&dst[3], &f, sizeof(float));
+            const int32_t remaining = bo_out.slot_remaining[sidx];
+            std::memcpy(&dst[7], &remaining, sizeof(float));
          }
-         std::vector<float> fnrm(12 * (size_t) md.n_faces);
+         slot_total += bo_out.slot_face.size();
+         all_fnrm.resize(12 * (face_base + md.n_faces), 0.0f);
          for (size_t f = 0; f < md.n_faces; f++) {
-            float *dst = fnrm.data() + 12 * f;
+            float *dst = all_fnrm.data() + 12 * (face_base + f);
             for (int kx = 0; kx < 3; kx++) {
                const float *nrm = bo_out.normals.data() + 3 * (size_t) md.indices[3 * f + kx];
                dst[4 * kx + 0] = nrm[0];
                dst[4 * kx + 1] = nrm[1];
                dst[4 * kx + 2] = nrm[2];
-               dst[4 * kx + 3] = 0.0f;
             }
          }
+         face_total += md.n_faces;
+
          s->objects.emplace_back();
          s->materials.push_back(md.material);
          if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
@@ -453,23 +476,14 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
          ho.n_leaves = bo_out.n_leaves;
          ho.n_slots = bo_out.slot_face.size();
          ho.max_depth = bo_out.max_depth;
-         int rc;
-         if ((rc = upload(bo_out.nodes.data(), bo_out.nodes.size() * sizeof(NodeRec), &ho.d_nodes, s)) ||
-             (rc = upload(tris.data(), tris.size() * sizeof(float), &ho.d_tris, s)) ||
-             (rc = upload(fnrm.data(), fnrm.size() * sizeof(float), &ho.d_fnrm, s))) {
-            release_scene(s);
-            return rc;
-         }
          DevObject &d = dev_objs[i];
-         d.nodes = ho.d_nodes;
-         d.tris = ho.d_tris;
-         d.fnrm = ho.d_fnrm;
          std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
          std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
-         d.root_link = bo_out.root_link;
-         d.root_cnt = bo_out.root_cnt;
-         d.root_is_leaf = bo_out.root_is_leaf;
+         d.root_entry = !bo_out.root_is_leaf ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
          d.shadow_distance = bo_out.shadow_distance;
+         d.face_base = (int32_t) face_base;
+         d.node_base = (int32_t) node_base;
+         d.slot_base = (int32_t) slot_base;
          d.mat.kind = md.material.kind;
          std::memcpy(d.mat.diffuse, md.material.diffuse, sizeof(d.mat.diffuse));
          std::memcpy(d.mat.specular, md.material.specular, sizeof(d.mat.specular));
@@ -480,9 +494,22 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
             s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
          }
       }
+      // one padding slot: a prefetching walk may read one slot past the last leaf
+      all_tris.resize(12 * (slot_total + 1), 0.0f);
+      const int32_t one = 1;
+      std::memcpy(&all_tris[12 * slot_total + 7], &one, sizeof(float));
    } catch (const std::bad_alloc &) {
       release_scene(s);
       return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
+   }
+   {
+      int rc;
+      if ((rc = upload(all_nodes.data(), all_nodes.size() * sizeof(NodeRec), &s->d_nodes, s)) ||
+          (rc = upload(all_tris.data(), all_tris.size() * sizeof(float), &s->d_tris, s)) ||
+          (rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s))) {
+         release_scene(s);
+         return rc;
+      }
    }
    float amax = 0.f;
    for (int c = 0; c < 3; c++) {
@@ -676,6 +703,14 @@ int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
    return MI355RT_OK;
 }
 
+int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[16])
+{
+   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+   if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
+   for (int q = 0; q < 16; q++) out[q] = scene->diag[q];
+   return MI355RT_OK;
+}
+
 int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, uint64_t n, const float *origins,
                        const float *directions, int32_t *hit_id, int32_t *hit_obj, float *hit_w, float *hit_point, float *hit_normal)
 {
@@ -702,6 +737,9 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    TraceBatchArgs a;
    std::memset(&a, 0, sizeof(a));
    a.sc.objs = scene->d_objs;
+   a.sc.nodes = scene->d_nodes;
+   a.sc.tris = scene->d_tris;
+   a.sc.fnrm = scene->d_fnrm;
    a.sc.n_objs = (int32_t) scene->objects.size();
    a.sc.epsilon = settings->epsilon;
    a.sc.near_plane = settings->near_plane;

@@ -3,6 +3,7 @@
 // SCENE (read-only during a frame).  One mesh object (= one KDTree of the reference,
 // bounds/KDTree.java) is three arrays:
 //
+// All objects' records are concatenated (links absolute); DevObject gives each object's root.
 //   nodes : one 64-byte record per INTERNAL node of the reference hierarchy, in DFS pre-order.
 //           A record carries the boxes and links of BOTH children, so one 4 x 128-bit fetch
 //           decides both child tests (the reference tests left.minMax / right.minMax at the
@@ -15,7 +16,8 @@
 //           leaf child holding cnt faces; link == LINK_NONE -> the reference's null child.
 //   tris  : one 48-byte slot per (leaf, face) pair, leaves in left-to-right DFS order, faces in
 //           the reference's stored order (straddlers are duplicated exactly as KDNode.java:58-69
-//           duplicates them).  slot = 3 x float4 { v0.xyz, faceId }, { v1.xyz, 0 }, { v2.xyz, 0 }.
+//           duplicates them).  slot = 3 x float4 { v0.xyz, faceId }, { v1.xyz, faces left in this leaf },
+//           { v2.xyz, 0 }; one zero padding slot follows the last leaf.
 //           Because leaves are laid out in DFS order, the first-slot index of a leaf is also the
 //           leaf's rank in the reference's fold order (the tie rule of KDNode.java:105,114).
 //   fnrm  : 48 bytes per FACE (not per slot): the three vertex normals, fetched once per final hit.
@@ -35,6 +37,7 @@
 namespace mi355rt {
 
 constexpr int32_t LINK_NONE = -1;
+constexpr int32_t STACK_EMPTY = 0x7fffffff;   // traversal cursor: nothing left (also the root entry of an empty mesh)
 constexpr int MAX_TREE_DEPTH = 22;   // build_opts.max_depth limit (the reference uses 20)
 constexpr int STACK_SLOTS = 24;      // >= MAX_TREE_DEPTH + 2
 constexpr int MAX_OBJECTS = 64;
@@ -55,20 +58,22 @@ struct DevMaterial {
 };
 
 struct DevObject {
-   const void *nodes;   // NodeRec[]
-   const void *tris;    // float4[3 * n_slots]
-   const void *fnrm;    // float4[3 * n_faces]
-   float bmin[3], bmax[3];
-   int32_t root_link, root_cnt;
-   int32_t root_is_leaf;
-   float shadow_distance;
+   float bmin[3], bmax[3];     // KDTree.minMax
+   int32_t root_entry;         // node index, ~first_slot when the root is a leaf, STACK_EMPTY for an empty mesh
+   float shadow_distance;      // KDTree.shadowDistance
+   int32_t face_base;          // first row of this object's faces in fnrm
+   int32_t node_base, slot_base;
    DevMaterial mat;
    int32_t pad_[2];
 };
 
-// what every kernel needs to walk the scene
+// what every kernel needs to walk the scene.  All objects share one node array and one slot array:
+// node links and leaf slots are absolute, so a wave's lanes may be inside different objects.
 struct SceneArgs {
    const DevObject *objs;
+   const void *nodes;   // NodeRec[]
+   const void *tris;    // float4[3 * (n_slots + 1)]
+   const void *fnrm;    // float4[3 * n_faces]
    int32_t n_objs;
    float epsilon, near_plane, far_plane;
    float scene_abs_max;   // max |coordinate| of the scene bounds (prune margin)
@@ -80,9 +85,10 @@ enum {
    CNT_SHADOW = 1,    // shadow list size
    CNT_SEC_A = 2,     // secondary queues (ping-pong)
    CNT_SEC_B = 3,
-   CNT_CURSOR0 = 4,   // work cursors, one per persistent launch (CNT_CURSOR0 + k)
-   CNT_STATS = 16,    // 6 x 64-bit stats counters start here (u32 pairs)
-   CNT_WORDS = 32
+   CNT_STATS = 16,    // 16 x 64-bit stats counters (u32 pairs): 6 public + walker diagnostics
+   CNT_CURSOR0 = 64,  // work cursors of the persistent launches: 8 (one per queue range) per launch
+   CNT_CURSOR_SETS = 8,
+   CNT_WORDS = 64 + 8 * 8
 };
 
 struct FrameArgs {

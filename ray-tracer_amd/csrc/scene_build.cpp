@@ -40,6 +40,7 @@ class Flattener {
          link = (int32_t) out_.slot_face.size();
          cnt = (int32_t) faces.size();
          out_.slot_face.insert(out_.slot_face.end(), faces.begin(), faces.end());
+         for (size_t k = 0; k < faces.size(); k++) out_.slot_remaining.push_back((int32_t) (faces.size() - k));
          out_.n_leaves++;
          return;
       }

@@ -17,6 +17,7 @@ struct BuildOptions {
 struct BuiltObject {
    std::vector<NodeRec> nodes;        // internal nodes, DFS pre-order
    std::vector<int32_t> slot_face;    // face id of every leaf slot, leaves in DFS order
+   std::vector<int32_t> slot_remaining;   // faces left in the slot's leaf, this slot included
    std::vector<float> normals;        // per-vertex normals actually used (given or synthesised)
    float bmin[3], bmax[3];            // KDTree.minMax
    float shadow_distance = 0.f;       // KDTree.shadowDistance

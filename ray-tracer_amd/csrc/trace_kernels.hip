@@ -165,112 +165,6 @@ __device__ __forceinline__ bool tri_test(const float4 A, const float4 B, const f
    return true;
 }
 
-// the running best of one object: distance, winning slot, first slot of its leaf
-struct Best {
-   float w;
-   int slot;   // < 0: none
-   int key;
-};
-
-// All faces of one leaf (KDNode.java:110-118) folded into the object's best hit.
-template <bool STATS, bool ANY>
-__device__ __forceinline__ void leaf_faces(const float4 *__restrict__ tris, int link, int cnt, const Ray &r, float eps,
-                                           float shadow_distance, Best &best, float &lim2, unsigned &n_tri)
-{
-   for (int s = 0; s < cnt; ++s) {
-      const float4 *t = tris + 3 * (size_t) (link + s);
-      const float4 A = t[0], B = t[1], C = t[2];
-      if (STATS) n_tri++;
-      float u, v, dist;
-      V3 P;
-      if (!tri_test(A, B, C, r, eps, u, v, P, dist)) continue;
-      if (!(dist > shadow_distance)) continue;
-      if (best.slot < 0 || dist < best.w || (dist == best.w && link > best.key)) {
-         best.w = dist;
-         best.slot = link + s;
-         best.key = link;
-         lim2 = fminf(lim2, prune_limit2(r, dist));
-         if (ANY) return;
-      }
-   }
-}
-
-// Closest accepted hit of one object = KDTree.getChildIntersection (bounds/KDTree.java:59-65).
-// `lim2_in` is an external squared prune limit (infinity when there is none).  With ANY the walk
-// stops at the first accepted candidate (only used where the host proved that equivalent).
-template <bool STATS, bool ANY>
-__device__ __forceinline__ void traverse_object(const DevObject &ob, const Ray &r, const SceneArgs &sc, bool want, float lim2_in,
-                                                Best &best, int *__restrict__ stack, unsigned &n_box, unsigned &n_tri)
-{
-   best.w = 0.0f;
-   best.slot = -1;
-   best.key = 0;
-   float lim2 = lim2_in;
-   int sp = 0;
-   const float4 *__restrict__ nodes = (const float4 *) ob.nodes;
-   const float4 *__restrict__ tris = (const float4 *) ob.tris;
-   const float nearp = sc.near_plane, farp = sc.far_plane, eps = sc.epsilon;
-   const float sd = ob.shadow_distance;
-
-   if (want) {
-      float te;
-      if (STATS) n_box++;
-      if (slab_test(r, nearp, farp, ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], te)) {
-         if (ob.root_is_leaf) {
-            leaf_faces<STATS, ANY>(tris, ob.root_link, ob.root_cnt, r, eps, sd, best, lim2, n_tri);
-         } else {
-            stack[0] = 0;
-            sp = 1;
-         }
-      }
-   }
-
-   while (sp > 0) {
-      --sp;
-      const int node = stack[sp * BLOCK_THREADS];
-      const float4 *rec = nodes + 4 * (size_t) node;
-      const float4 a = rec[0], b = rec[1], c = rec[2];
-      const int4 d = *(const int4 *) (rec + 3);
-      float tl = 0.0f, tr = 0.0f;
-      bool lok = false, rok = false;
-      if (d.x != LINK_NONE) {
-         if (STATS) n_box++;
-         lok = slab_test(r, nearp, farp, a.x, a.y, a.z, a.w, b.x, b.y, tl) && !(origin_box_dist2(r, a.x, a.y, a.z, a.w, b.x, b.y) > lim2);
-      }
-      if (d.y != LINK_NONE) {
-         if (STATS) n_box++;
-         rok = slab_test(r, nearp, farp, b.z, b.w, c.x, c.y, c.z, c.w, tr) && !(origin_box_dist2(r, b.z, b.w, c.x, c.y, c.z, c.w) > lim2);
-      }
-      // nearest child first; `swap` only chooses an order, never whether a child is visited
-      const bool swap = lok && rok && (tr < tl);
-      const int n_link = swap ? d.y : d.x, n_cnt = swap ? d.w : d.z;
-      const int f_link = swap ? d.x : d.y, f_cnt = swap ? d.z : d.w;
-      const bool n_ok = swap ? rok : lok, f_ok = swap ? lok : rok;
-      // leaf children are tested on the spot (they are small); internal children go on the stack
-      if (n_ok && n_cnt > 0) leaf_faces<STATS, ANY>(tris, n_link, n_cnt, r, eps, sd, best, lim2, n_tri);
-      if (ANY && best.slot >= 0) break;
-      if (f_ok && f_cnt > 0) leaf_faces<STATS, ANY>(tris, f_link, f_cnt, r, eps, sd, best, lim2, n_tri);
-      if (ANY && best.slot >= 0) break;
-      if (f_ok && f_cnt == 0) {
-         stack[sp * BLOCK_THREADS] = f_link;
-         ++sp;
-      }
-      if (n_ok && n_cnt == 0) {
-         stack[sp * BLOCK_THREADS] = n_link;
-         ++sp;
-      }
-   }
-}
-
-// a wave takes the next 64 queue entries; false once the queue is drained (every wave gets here)
-__device__ __forceinline__ bool next_batch(unsigned *cursor, unsigned count, unsigned &base)
-{
-   unsigned b = 0;
-   if ((threadIdx.x & 63) == 0) b = atomicAdd(cursor, 64u);
-   base = (unsigned) __builtin_amdgcn_readfirstlane((int) b);
-   return base < count;
-}
-
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -282,7 +176,16 @@ __device__ __forceinline__ void add_stat(uint32_t *counters, int which, unsigned
    const unsigned long long s = wave_sum((unsigned long long) v);
    if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long *) (counters + CNT_STATS) + which, s);
 }
-enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, ST_HITS = 5 };
+enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, ST_HITS = 5,
+       // walker diagnostics (collect_stats builds only): lane-trips and wave-trips of each phase
+       ST_NODE_LANE = 6, ST_NODE_WAVE = 7, ST_LEAF_LANE = 8, ST_LEAF_WAVE = 9, ST_OUTER_WAVE = 10, ST_REFILL = 11 };
+
+// true on exactly one of the currently active lanes
+__device__ __forceinline__ bool first_active_lane()
+{
+   const unsigned long long m = __ballot(1);
+   return (int) (threadIdx.x & 63) == (__ffsll((unsigned long long) m) - 1);
+}
 
 // appends one record per lane with `push` set; returns the lane's index (wave-aggregated atomic)
 __device__ __forceinline__ unsigned queue_push(unsigned *count, bool push)
@@ -574,85 +477,428 @@ __global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs
    }
 }
 
-// ---------------------------------------------------------------- trace (closest hit)
-// Camera.getClosestIntersection (Camera.java:193-215) for every ray of a queue.  aux of a ray is
-// the mirror object to skip (-1: none) in its low 16 bits.
-struct TraceArgs {
+// ---------------------------------------------------------------- the walker
+// One kernel walks every kind of ray:
+//   MODE_CLOSEST     Camera.getClosestIntersection (Camera.java:193-215) for the rays of a queue;
+//                    aux of a ray = the mirror object to skip (-1: none) in its low 16 bits
+//   MODE_SHADOW      RTStatics.shadowIntersects (RTStatics.java:617-639) for the paths of the
+//                    shadow list: per object the closest accepted hit, then the before-the-light test
+//   MODE_SHADOW_ANY  the same where the host proved that any accepted hit occludes (api.cpp)
+//
+// Persistent wave64s.  A LANE that has finished its ray takes the next one from the queue without
+// waiting for the other 63 (rays differ several-fold in length; batch-at-a-time left 5 of 6 lanes
+// idle).  A lane is therefore a small state machine: {ray, current object k, cursor `cur`, stack
+// depth, best of object k, best of the scene}.  All objects share one node array and one slot array
+// (links are absolute), so lanes of one wave may be inside different objects.
+//
+// The queue is cut into 8 contiguous ranges with one cursor each; a wave starts on range
+// blockIdx % 8 (workgroups b and b + 8 share an XCD, hence an L2) and moves on to the next range
+// when its own is drained.  Queue order follows image order, so each L2 mostly sees one band of the
+// image.  Placement only affects speed: every ray is claimed exactly once whatever runs where.
+enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2 };
+constexpr int REFILL_MIN = 16;   // refill once this many lanes are idle (or all of them)
+
+struct WalkArgs {
    SceneArgs sc;
-   const float *rays;
+   const float *rays;        // MODE_CLOSEST: the queue
    float *hits;
    int32_t *hit_obj;
+   const float *hits0;       // shadow modes: primary hits, material/flag records, list of paths
+   float *mat0;
+   const uint32_t *shadow;
+   float light[3];
    uint32_t *counters;
    int32_t count_index, cursor_index;
    int32_t stats;
 };
 
-template <bool STATS>
-__global__ __launch_bounds__(BLOCK_THREADS) void trace_kernel(const TraceArgs a)
+// lane roles
+enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
+constexpr int STEAL_MIN = 8;        // while the queue still has rays: steal once this many lanes are idle
+constexpr bool FETCH_DMA = false;   // record fetch through LDS (global_load_lds) instead of per-lane loads
+
+template <bool STATS, int MODE>
+__global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
 {
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
-   int *stack = s_stack + threadIdx.x;
+   __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
+   __shared__ float4 s_stage[FETCH_DMA ? 4 * BLOCK_THREADS : 1];      // 64 B per lane: this trip's record
    const int lane = threadIdx.x & 63;
+   const int wave_base = threadIdx.x & ~63;
+   int *__restrict__ stack = s_stack + threadIdx.x;
+   volatile int *list = s_list + wave_base;
+   float4 *stage = s_stage + (FETCH_DMA ? 4 * wave_base : 0);
+   const unsigned long long lanes_below = (1ull << lane) - 1ull;
    const unsigned count = a.counters[a.count_index];
-   unsigned n_box = 0, n_tri = 0, n_hit = 0;
-   unsigned base;
-   while (next_batch(a.counters + a.cursor_index, count, base)) {
-      const unsigned i = base + (unsigned) lane;
-      const bool active = i < count;
-      V3 o = mk3(0, 0, 0), d = mk3(0, 0, -1);
-      int mirror = -1;
-      if (active) {
-         const float4 *q = (const float4 *) a.rays + 2 * (size_t) i;
-         const float4 r0 = q[0], r1 = q[1];
-         o = mk3(r0.x, r0.y, r0.z);
-         d = mk3(r1.x, r1.y, r1.z);
-         mirror = (int) (short) (__float_as_int(r1.w) & 0xffff);
-      }
-      Ray r;
-      make_ray(r, o, d, a.sc.scene_abs_max);
-      float best_w = 0.0f;
-      int best_slot = -1, best_obj = -1;
-      for (int k = 0; k < a.sc.n_objs; k++) {
-         const DevObject &ob = a.sc.objs[k];
-         const bool want = active && (k != mirror);
-         const float lim2_in = best_obj >= 0 ? prune_limit2(r, best_w) : __builtin_inff();
-         Best h;
-         traverse_object<STATS, false>(ob, r, a.sc, want, lim2_in, h, stack, n_box, n_tri);
-         if (want && h.slot >= 0 && (h.w > a.sc.epsilon) && (best_obj < 0 || h.w < best_w)) {   // Camera.java:208
-            best_w = h.w;
-            best_slot = h.slot;
-            best_obj = k;
+   uint32_t *cursors = a.counters + a.cursor_index;
+   const float4 *__restrict__ nodes = (const float4 *) a.sc.nodes;
+   const float4 *__restrict__ tris = (const float4 *) a.sc.tris;
+   const float nearp = a.sc.near_plane, farp = a.sc.far_plane, eps = a.sc.epsilon;
+   const V3 light = mk3(a.light[0], a.light[1], a.light[2]);
+   const int n_objs = a.sc.n_objs;
+
+   // wave-uniform
+   const int home = (int) (blockIdx.x & 7u);
+   int attempt = 0;
+   bool exhausted = false;
+   // per lane
+   int role = ROLE_IDLE;
+   int owner = lane;      // the lane whose ray this lane is walking (itself unless ROLE_HELPER)
+   int pending = 0;       // ROLE_OWNER: helpers still walking parts of my current object
+   unsigned qi = 0;
+   Ray r;
+   make_ray(r, mk3(0, 0, 0), mk3(0, 0, -1), 0.0f);
+   int mirror = -1, k = -1, cur = STACK_EMPTY;
+   int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
+   float sd = 0.0f, lim2 = 0.0f;
+   float ob_w = 0.0f, best_w = 0.0f;
+   int ob_slot = -1, ob_key = 0, best_slot = -1, best_obj = -1;
+   bool occluded = false;
+   int s = 0, leaf0 = 0;   // current slot / first slot of the current leaf (valid while cur < 0)
+   unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0;
+   unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
+
+   for (;;) {
+      if (STATS && lane == 0) d_outer++;
+      if (__ballot(cur == STACK_EMPTY) != 0ull) {
+         // ---- (1) helpers that finished their subtree hand (w, slot, leaf) to the ray's owner, which
+         // folds it in with the same order-independent rule the leaves use
+         unsigned long long fin = __ballot(role == ROLE_HELPER && cur == STACK_EMPTY);
+         while (fin != 0ull) {
+            const int h = __ffsll((unsigned long long) fin) - 1;
+            fin &= fin - 1ull;
+            const int o = __shfl(owner, h, 64);
+            const float hw = __shfl(ob_w, h, 64);
+            const int hs = __shfl(ob_slot, h, 64), hk = __shfl(ob_key, h, 64);
+            if (lane == o) {
+               --pending;
+               if (hs >= 0 && (ob_slot < 0 || hw < ob_w || (hw == ob_w && hk > ob_key))) {
+                  ob_w = hw;
+                  ob_slot = hs;
+                  ob_key = hk;
+                  lim2 = fminf(lim2, prune_limit2(r, hw));
+               }
+            }
+         }
+         if (role == ROLE_HELPER && cur == STACK_EMPTY) {
+            role = ROLE_IDLE;
+            owner = lane;
+         }
+
+         // ---- (2) an owner whose walk of object k has ended (and whose helpers are all back): fold the
+         // object's result, enter the next object or retire the ray
+         if (role == ROLE_OWNER && cur == STACK_EMPTY && pending == 0) {
+            if (k >= 0 && ob_slot >= 0) {
+               if (MODE == MODE_CLOSEST) {
+                  if ((ob_w > eps) && (best_obj < 0 || ob_w < best_w)) {   // Camera.java:208
+                     best_w = ob_w;
+                     best_slot = ob_slot;
+                     best_obj = k;
+                  }
+               } else if (MODE == MODE_SHADOW_ANY) {
+                  occluded = true;
+               } else if (ob_w > eps) {   // RTStatics.java:628-633
+                  const float4 *t = tris + 3 * (size_t) ob_slot;
+                  float u, v, dist;
+                  V3 P;
+                  (void) tri_test(t[0], t[1], t[2], r, eps, u, v, P, dist);
+                  if (ob_w < distance3(P, light) + eps) occluded = true;
+               }
+            }
+            int nk = k + 1;
+            if (MODE == MODE_CLOSEST && nk == mirror) ++nk;
+            const bool done = (nk >= n_objs) || (MODE != MODE_CLOSEST && occluded);
+            if (!done) {
+               k = nk;
+               const DevObject *ob = a.sc.objs + k;
+               sd = ob->shadow_distance;
+               ob_slot = -1;
+               ob_w = 0.0f;
+               ob_key = 0;
+               sp = bot = 0;
+               lim2 = (MODE == MODE_CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w) : __builtin_inff();
+               float te;
+               if (STATS) n_box++;
+               if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {
+                  cur = ob->root_entry;   // KDTree.getChildIntersection (bounds/KDTree.java:59-65)
+                  s = leaf0 = ~cur;
+               }
+            } else {
+               if (MODE == MODE_CLOSEST) {
+                  float4 h0 = make_float4(0, 0, 0, 0), h1 = make_float4(0, 0, 0, __int_as_float(-1));
+                  if (best_obj >= 0) {
+                     // the winner's point, barycentrics and normal, recomputed once (same arithmetic => same bits)
+                     const float4 *t = tris + 3 * (size_t) best_slot;
+                     const float4 A = t[0], B = t[1], C = t[2];
+                     float u = 0, v = 0, dist = 0;
+                     V3 P = mk3(0, 0, 0);
+                     (void) tri_test(A, B, C, r, eps, u, v, P, dist);
+                     const int face = __float_as_int(A.w);
+                     const float4 *fn = (const float4 *) a.sc.fnrm + 3 * ((size_t) a.sc.objs[best_obj].face_base + (size_t) face);
+                     const float4 n0 = fn[0], n1 = fn[1], n2 = fn[2];
+                     const float wb = 1.0f - u - v;   // Triangle.java:126-129, not renormalised
+                     h0 = make_float4(P.x, P.y, P.z, dist);
+                     h1 = make_float4(wb * n0.x + u * n1.x + v * n2.x, wb * n0.y + u * n1.y + v * n2.y,
+                                      wb * n0.z + u * n1.z + v * n2.z, __int_as_float(face));
+                     if (STATS) n_hit++;
+                  }
+                  float4 *hq = (float4 *) a.hits + 2 * (size_t) qi;
+                  hq[0] = h0;
+                  hq[1] = h1;
+                  a.hit_obj[qi] = best_obj;
+               } else {
+                  a.mat0[4 * (size_t) qi + 3] = occluded ? 1.0f : 0.0f;
+               }
+               role = ROLE_IDLE;
+            }
+         }
+
+         // ---- (3) idle lanes take new rays from the queue
+         const unsigned long long idle = __ballot(role == ROLE_IDLE);
+         if (idle != 0ull && !exhausted && (__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
+            const unsigned want_n = (unsigned) __popcll(idle);
+            if (STATS && lane == 0) d_refill++;
+            unsigned base = 0, limit = 0;
+            bool got = false;
+            while (attempt < 8) {
+               const unsigned rg = (unsigned) (home + attempt) & 7u;
+               const unsigned lo = (unsigned) ((unsigned long long) count * rg / 8ull);
+               const unsigned hi = (unsigned) ((unsigned long long) count * (rg + 1u) / 8ull);
+               unsigned b = 0;
+               if (lane == 0) b = atomicAdd(cursors + rg, want_n);
+               b = (unsigned) __builtin_amdgcn_readfirstlane((int) b);
+               if (b < hi - lo) {
+                  base = lo + b;
+                  limit = hi;
+                  got = true;
+                  break;
+               }
+               ++attempt;
+            }
+            if (!got) {
+               exhausted = true;
+            } else if (role == ROLE_IDLE) {
+               const unsigned my = base + (unsigned) __popcll(idle & lanes_below);
+               if (my < limit) {
+                  qi = my;
+                  V3 o, d;
+                  if (MODE == MODE_CLOSEST) {
+                     const float4 *q = (const float4 *) a.rays + 2 * (size_t) my;
+                     const float4 r0 = q[0], r1 = q[1];
+                     o = mk3(r0.x, r0.y, r0.z);
+                     d = mk3(r1.x, r1.y, r1.z);
+                     mirror = (int) (short) (__float_as_int(r1.w) & 0xffff);
+                  } else {
+                     qi = a.shadow[my];   // the path
+                     const float4 *hq = (const float4 *) a.hits0 + 2 * (size_t) qi;
+                     const float4 h0 = hq[0], h1 = hq[1];
+                     const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z);
+                     d = normalize3(normalize3(sub3(light, P)));   // RTStatics.java:619-620, then the Ray ctor
+                     o = add3(P, scale3(N, eps));                  // RTStatics.offsetPosition
+                     mirror = -1;
+                  }
+                  make_ray(r, o, d, a.sc.scene_abs_max);
+                  role = ROLE_OWNER;
+                  owner = lane;
+                  pending = 0;
+                  k = -1;
+                  sp = bot = 0;
+                  best_obj = -1;
+                  best_slot = -1;
+                  best_w = 0.0f;
+                  occluded = false;
+                  if (STATS) n_ray++;
+               }
+            }
+         }
+
+         // ---- (4) lanes still idle steal work inside the wave: the BOTTOM stack entry (the largest
+         // pending subtree) of a busy lane, walked with a copy of that lane's ray.  Which lane walks a
+         // subtree cannot change the result: the fold is order independent (see the header comment).
+         const unsigned long long thieves = __ballot(role == ROLE_IDLE);
+         const unsigned long long victims = __ballot(role != ROLE_IDLE && sp > bot);
+         if (thieves != 0ull && victims != 0ull && (exhausted || __popcll(thieves) >= STEAL_MIN)) {
+            const int n_pairs = min(__popcll(thieves), __popcll(victims));
+            const int v_rank = __popcll(victims & lanes_below), t_rank = __popcll(thieves & lanes_below);
+            const bool is_victim = ((victims >> lane) & 1ull) != 0ull && v_rank < n_pairs;
+            const bool is_thief = role == ROLE_IDLE && t_rank < n_pairs;
+            if (is_victim) list[v_rank] = lane;
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the list is written before it is read (one wave, in order)
+            const int v = is_thief ? list[t_rank] : lane;
+            const int v_bot = __shfl(bot, v, 64);
+            const int entry = s_stack[min(v_bot, STACK_SLOTS - 1) * BLOCK_THREADS + wave_base + v];
+            const int v_owner = __shfl(owner, v, 64), v_k = __shfl(k, v, 64);
+            const float v_sd = __shfl(sd, v, 64), v_lim2 = __shfl(lim2, v, 64);
+            const float ox = __shfl(r.o.x, v, 64), oy = __shfl(r.o.y, v, 64), oz = __shfl(r.o.z, v, 64);
+            const float dx = __shfl(r.d.x, v, 64), dy = __shfl(r.d.y, v, 64), dz = __shfl(r.d.z, v, 64);
+            const float ix = __shfl(r.inv.x, v, 64), iy = __shfl(r.inv.y, v, 64), iz = __shfl(r.inv.z, v, 64);
+            const float v_margin = __shfl(r.abs_margin, v, 64);
+            if (is_victim) ++bot;
+            if (is_thief) {
+               role = ROLE_HELPER;
+               owner = v_owner;
+               k = v_k;
+               sd = v_sd;
+               lim2 = v_lim2;
+               r.o = mk3(ox, oy, oz);
+               r.d = mk3(dx, dy, dz);
+               r.inv = mk3(ix, iy, iz);
+               r.abs_margin = v_margin;
+               cur = entry;
+               s = leaf0 = ~cur;
+               sp = bot = 0;
+               ob_slot = -1;
+               ob_w = 0.0f;
+               ob_key = 0;
+               if (STATS) d_steal++;
+            }
+            unsigned long long tm = __ballot(is_thief);
+            while (tm != 0ull) {
+               const int t = __ffsll((unsigned long long) tm) - 1;
+               tm &= tm - 1ull;
+               const int o = __shfl(owner, t, 64);
+               if (lane == o) ++pending;
+            }
+         }
+         // prune limits found on the owner's side reach its helpers here
+         lim2 = fminf(lim2, __shfl(lim2, owner, 64));
+
+         if (__ballot(role != ROLE_IDLE) == 0ull) {
+            if (exhausted) break;
+            continue;
          }
       }
-      if (active) {
-         float4 h0 = make_float4(0, 0, 0, 0), h1 = make_float4(0, 0, 0, __int_as_float(-1));
-         if (best_obj >= 0) {
-            // the winner's point, barycentrics and normal, recomputed once (same arithmetic => same bits)
-            const DevObject *ob = a.sc.objs + best_obj;
-            const float4 *t = (const float4 *) ob->tris + 3 * (size_t) best_slot;
-            const float4 A = t[0], B = t[1], C = t[2];
-            float u = 0, v = 0, dist = 0;
-            V3 P = mk3(0, 0, 0);
-            (void) tri_test(A, B, C, r, a.sc.epsilon, u, v, P, dist);
-            const int face = __float_as_int(A.w);
-            const float4 *fn = (const float4 *) ob->fnrm + 3 * (size_t) face;
-            const float4 n0 = fn[0], n1 = fn[1], n2 = fn[2];
-            const float wb = 1.0f - u - v;   // Triangle.java:126-129, not renormalised
-            h0 = make_float4(P.x, P.y, P.z, dist);
-            h1 = make_float4(wb * n0.x + u * n1.x + v * n2.x, wb * n0.y + u * n1.y + v * n2.y, wb * n0.z + u * n1.z + v * n2.z,
-                             __int_as_float(face));
-            n_hit++;
+
+      // ---- one step per lane: an internal node (C) or one face of a leaf (D)
+      const bool is_node = (unsigned) cur < (unsigned) STACK_EMPTY;
+      const bool is_leaf = cur < 0;
+      float4 na, nb, nc, A, B, C;
+      int4 nd;
+      if (FETCH_DMA) {
+         // Every lane needs ONE record this trip: a 64-byte node or a 48-byte leaf slot, at an address
+         // of its own.  Four neighbouring lanes fetch one owner's record as one contiguous 64 bytes,
+         // straight into LDS (global_load_lds, 16 B per lane): instruction j serves lanes 16j..16j+15,
+         // so the wave's 64 records take 4 instructions of 16 x 64-byte segments each.  Every lane then
+         // reads its own record back from LDS.  The 16-byte chunks of a record are stored rotated by
+         // (lane >> 2) & 3 so that the 128-bit LDS reads are bank-conflict free.  (A leaf slot's 4th
+         // chunk is the first 16 bytes of the next slot: read, never used.)
+         const int code = is_node ? cur : (is_leaf ? ~s : 0);   // >= 0: node index, < 0: ~slot
+#pragma unroll
+         for (int j = 0; j < 4; j++) {
+            const int rec_lane = j * 16 + (lane >> 2);
+            const int ocode = __shfl(code, rec_lane, 64);
+            const int chunk = (lane & 3) ^ ((rec_lane >> 2) & 3);
+            const char *src = ocode >= 0 ? (const char *) nodes + (size_t) ocode * 64 : (const char *) tris + (size_t) (~ocode) * 48;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + chunk * 16),
+                                             (__attribute__((address_space(3))) void *) (stage + j * 64), 16, 0, 0);
          }
-         float4 *hq = (float4 *) a.hits + 2 * (size_t) i;
-         hq[0] = h0;
-         hq[1] = h1;
-         a.hit_obj[i] = best_obj;
+         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+         const int rot = (lane >> 2) & 3;
+         const float4 *mine = stage + lane * 4;
+         const float4 q0 = mine[0 ^ rot], q1 = mine[1 ^ rot], q2 = mine[2 ^ rot], q3 = mine[3 ^ rot];
+         na = A = q0;
+         nb = B = q1;
+         nc = C = q2;
+         nd = make_int4(__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w));
+      } else {
+         // both fetches are issued up front, for every lane (lanes not in that state read record 0), so
+         // that their latencies overlap and the compiler has no branch to sink them under
+         const float4 *rec = nodes + 4 * (size_t) (is_node ? cur : 0);
+         const float4 *t = tris + 3 * (size_t) (is_leaf ? s : 0);
+         na = rec[0];
+         nb = rec[1];
+         nc = rec[2];
+         nd = *(const int4 *) (rec + 3);
+         A = t[0];
+         B = t[1];
+         C = t[2];
+      }
+
+      if (is_node) {
+         // (C) both children of one internal node
+         if (STATS) {
+            d_node_lane++;
+            if (first_active_lane()) d_node_wave++;
+         }
+         float tl = 0.0f, tr = 0.0f;
+         bool lok = false, rok = false;
+         if (nd.x != LINK_NONE) {
+            if (STATS) n_box++;
+            lok = slab_test(r, nearp, farp, na.x, na.y, na.z, na.w, nb.x, nb.y, tl) &&
+                  !(origin_box_dist2(r, na.x, na.y, na.z, na.w, nb.x, nb.y) > lim2);
+         }
+         if (nd.y != LINK_NONE) {
+            if (STATS) n_box++;
+            rok = slab_test(r, nearp, farp, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w, tr) &&
+                  !(origin_box_dist2(r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w) > lim2);
+         }
+         const int le = nd.z > 0 ? ~nd.x : nd.x;   // stack / cursor form of each child: leaf = ~first_slot
+         const int re = nd.w > 0 ? ~nd.y : nd.y;
+         if (lok && rok) {
+            // nearest child first; the order never decides WHETHER a child is visited
+            const bool swap = tr < tl;
+            cur = swap ? re : le;
+            stack[sp * BLOCK_THREADS] = swap ? le : re;
+            ++sp;
+         } else if (lok) {
+            cur = le;
+         } else if (rok) {
+            cur = re;
+         } else if (sp > bot) {
+            --sp;
+            cur = stack[sp * BLOCK_THREADS];
+         } else {
+            cur = STACK_EMPTY;
+         }
+         s = leaf0 = ~cur;
+      }
+
+      if (is_leaf) {
+         // (D) one face of a leaf (KDNode.java:110-118), folded into object k's best.  The slot's second
+         // float4 carries in .w how many faces of the leaf remain from that slot on.
+         if (STATS) {
+            n_tri++;
+            if (first_active_lane()) d_leaf_wave++;
+         }
+         float u, v, dist;
+         V3 P;
+         bool stop = __float_as_int(B.w) <= 1;
+         if (tri_test(A, B, C, r, eps, u, v, P, dist) && (dist > sd) &&
+             (ob_slot < 0 || dist < ob_w || (dist == ob_w && leaf0 > ob_key))) {
+            ob_w = dist;
+            ob_slot = s;
+            ob_key = leaf0;
+            lim2 = fminf(lim2, prune_limit2(r, dist));
+            if (MODE == MODE_SHADOW_ANY) {
+               stop = true;
+               sp = bot;
+            }
+         }
+         ++s;
+         if (stop) {
+            if (sp > bot) {
+               --sp;
+               cur = stack[sp * BLOCK_THREADS];
+            } else {
+               cur = STACK_EMPTY;
+            }
+            s = leaf0 = ~cur;
+         }
       }
    }
+
    if (STATS) {
       add_stat(a.counters, ST_BOX, n_box);
       add_stat(a.counters, ST_TRI, n_tri);
+      if (MODE != MODE_CLOSEST) add_stat(a.counters, ST_SHADOW, n_ray);
       add_stat(a.counters, ST_HITS, a.stats == 2 ? n_hit : 0u);
+      add_stat(a.counters, ST_NODE_LANE, d_node_lane);
+      add_stat(a.counters, ST_NODE_WAVE, d_node_wave);
+      add_stat(a.counters, ST_LEAF_LANE, n_tri);
+      add_stat(a.counters, ST_LEAF_WAVE, d_leaf_wave);
+      add_stat(a.counters, ST_OUTER_WAVE, d_outer);
+      add_stat(a.counters, ST_REFILL, d_refill);
+      add_stat(a.counters, 12, d_steal);
    }
 }
 
@@ -758,74 +1004,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
    }
    }
    if (p.stats) add_stat(p.counters, ST_SECONDARY, n_sec);
-}
-
-// ---------------------------------------------------------------- shadow rays
-// RTStatics.shadowIntersects (RTStatics.java:617-639) for every path in the shadow list; the flag
-// goes into mat0[path].w.
-struct ShadowArgs {
-   SceneArgs sc;
-   const float *hits0;
-   float *mat0;
-   const uint32_t *shadow;
-   uint32_t *counters;
-   int32_t cursor_index;
-   float light[3];
-   int32_t stats;
-};
-
-template <bool STATS, bool ANY>
-__global__ __launch_bounds__(BLOCK_THREADS) void shadow_kernel(const ShadowArgs a)
-{
-   __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
-   int *stack = s_stack + threadIdx.x;
-   const int lane = threadIdx.x & 63;
-   const unsigned count = a.counters[CNT_SHADOW];
-   const V3 light = mk3(a.light[0], a.light[1], a.light[2]);
-   unsigned n_box = 0, n_tri = 0, n_ray = 0;
-   unsigned base;
-   while (next_batch(a.counters + a.cursor_index, count, base)) {
-      const unsigned i = base + (unsigned) lane;
-      const bool active = i < count;
-      V3 o = mk3(0, 0, 0), d = mk3(0, 0, -1);
-      unsigned path = 0;
-      if (active) {
-         path = a.shadow[i];
-         const float4 *hq = (const float4 *) a.hits0 + 2 * (size_t) path;
-         const float4 h0 = hq[0], h1 = hq[1];
-         const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z);
-         d = normalize3(normalize3(sub3(light, P)));   // RTStatics.java:619-620, then the Ray ctor
-         o = add3(P, scale3(N, a.sc.epsilon));         // RTStatics.offsetPosition
-         n_ray++;
-      }
-      Ray r;
-      make_ray(r, o, d, a.sc.scene_abs_max);
-      bool occluded = false;
-      for (int k = 0; k < a.sc.n_objs; k++) {
-         const DevObject &ob = a.sc.objs[k];
-         const bool want = active && !occluded;
-         Best h;
-         traverse_object<STATS, ANY>(ob, r, a.sc, want, __builtin_inff(), h, stack, n_box, n_tri);
-         if (want && h.slot >= 0) {
-            if (ANY) {
-               occluded = true;   // host-proven equivalent (api.cpp: shadow_any_hit)
-            } else if (h.w > a.sc.epsilon) {   // RTStatics.java:628-633
-               const float4 *t = (const float4 *) ob.tris + 3 * (size_t) h.slot;
-               float u, v, dist;
-               V3 P;
-               (void) tri_test(t[0], t[1], t[2], r, a.sc.epsilon, u, v, P, dist);
-               const float light_distance = distance3(P, light);
-               if (h.w < light_distance + a.sc.epsilon) occluded = true;
-            }
-         }
-      }
-      if (active) a.mat0[4 * (size_t) path + 3] = occluded ? 1.0f : 0.0f;
-   }
-   if (STATS) {
-      add_stat(a.counters, ST_SHADOW, n_ray);
-      add_stat(a.counters, ST_BOX, n_box);
-      add_stat(a.counters, ST_TRI, n_tri);
-   }
 }
 
 // ---------------------------------------------------------------- Phong combine
@@ -939,7 +1117,7 @@ unsigned blocks_for(unsigned long long n) { return (unsigned) ((n + BLOCK_THREAD
 // persistent grids: enough resident waves to fill the chip, never more than the work can use
 unsigned persistent_grid(int n_cus, unsigned long long max_items)
 {
-   const unsigned long long want = (unsigned long long) n_cus * 6ull;   // 6 blocks of 4 waves per CU (LDS-limited)
+   const unsigned long long want = (unsigned long long) n_cus * (FETCH_DMA ? 4ull : 6ull);   // blocks of 4 waves per CU (LDS: 25 KB, 41 KB with staging)
    const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
    return (unsigned) (need < want ? (need ? need : 1ull) : want);
 }
@@ -954,22 +1132,35 @@ unsigned bounded_grid(int n_cus, unsigned long long max_items)
 
 }   // namespace
 
+namespace {
+
+template <int MODE>
+hipError_t launch_walk(const WalkArgs &a, unsigned grid, bool stats, hipStream_t stream)
+{
+   if (stats) hipLaunchKernelGGL((walk_kernel<true, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   else hipLaunchKernelGGL((walk_kernel<false, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   return hipGetLastError();
+}
+
+}   // namespace
+
 hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
                         int cursor_index, unsigned long long max_items, int n_cus, int stats, hipStream_t stream)
 {
-   TraceArgs a;
+   WalkArgs a;
    a.sc = sc;
    a.rays = rays;
    a.hits = hits;
    a.hit_obj = hit_obj;
+   a.hits0 = nullptr;
+   a.mat0 = nullptr;
+   a.shadow = nullptr;
+   a.light[0] = a.light[1] = a.light[2] = 0.0f;
    a.counters = counters;
    a.count_index = count_index;
    a.cursor_index = cursor_index;
    a.stats = stats;
-   const unsigned grid = persistent_grid(n_cus, max_items);
-   if (stats) hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
-   else hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
-   return hipGetLastError();
+   return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats != 0, stream);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
@@ -996,27 +1187,24 @@ hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const 
 
 hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long long max_items, int n_cus, hipStream_t stream)
 {
-   ShadowArgs a;
+   WalkArgs a;
    a.sc = p.sc;
+   a.rays = nullptr;
+   a.hits = nullptr;
+   a.hit_obj = nullptr;
    a.hits0 = p.hits0;
    a.mat0 = p.mat0;
    a.shadow = p.shadow;
-   a.counters = p.counters;
-   a.cursor_index = cursor_index;
    a.light[0] = p.light_origin[0];
    a.light[1] = p.light_origin[1];
    a.light[2] = p.light_origin[2];
+   a.counters = p.counters;
+   a.count_index = CNT_SHADOW;
+   a.cursor_index = cursor_index;
    a.stats = p.stats;
    const unsigned grid = persistent_grid(n_cus, max_items);
-   const dim3 g(grid), b(BLOCK_THREADS);
-   if (p.stats) {
-      if (p.shadow_any_hit) hipLaunchKernelGGL((shadow_kernel<true, true>), g, b, 0, stream, a);
-      else hipLaunchKernelGGL((shadow_kernel<true, false>), g, b, 0, stream, a);
-   } else {
-      if (p.shadow_any_hit) hipLaunchKernelGGL((shadow_kernel<false, true>), g, b, 0, stream, a);
-      else hipLaunchKernelGGL((shadow_kernel<false, false>), g, b, 0, stream, a);
-   }
-   return hipGetLastError();
+   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, p.stats != 0, stream);
+   return launch_walk<MODE_SHADOW>(a, grid, p.stats != 0, stream);
 }
 
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream)

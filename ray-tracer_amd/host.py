@@ -352,6 +352,11 @@ class Camera:
         _abi.check(self._lib.mi355rt_frame_stats(self.scene._handle, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _abi.Stats._fields_}
 
+    def debug_counters(self):
+        out = (C.c_uint64 * 16)()
+        _abi.check(self._lib.mi355rt_debug_counters(self.scene._handle, out))
+        return list(out)
+
     def getClosestIntersection(self, origins, directions):
         """Camera.getClosestIntersection(null, origin, direction, null, 0) for arrays of rays."""
         o = _f32(origins).reshape(-1, 3)

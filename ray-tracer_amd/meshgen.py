@@ -1,6 +1,6 @@
 """Seeded procedural stand-ins for the Stanford scans (no PLY models exist in this pipeline).
 
-SURVEY.md 8(d): a lat-long sphere of the needed resolution with a seeded multi-octave radial
+SURVEY.md 8(d): a cube-sphere grid of the needed resolution with a seeded multi-octave radial
 displacement (surface-like coherence, as a scanned statue has), stretched per axis, scaled to the
 model's span, and topped up to the exact face count.  Inputs only -- nothing here is on the hot path.
 """
@@ -17,69 +17,72 @@ STANFORD = {
 }
 
 
-def _uv_sphere(rings, segs):
-    """Unit lat-long sphere: 2 poles + (rings-1)*segs vertices, 2*segs*(rings-1) faces (CCW outward)."""
-    theta = np.pi * np.arange(1, rings, dtype=np.float64) / rings        # polar angle of each ring
-    phi = 2.0 * np.pi * np.arange(segs, dtype=np.float64) / segs
-    T, P = np.meshgrid(theta, phi, indexing="ij")
-    ang = np.concatenate([[[0.0, 0.0]], np.stack([T.ravel(), P.ravel()], axis=1), [[np.pi, 0.0]]])
-    south = ang.shape[0] - 1
-
-    def vid(r, s):   # ring r in [0, rings-2], segment s
-        return 1 + r * segs + (s % segs)
-
-    s = np.arange(segs)
-    faces = [np.stack([np.zeros(segs, dtype=np.int64), vid(0, s), vid(0, s + 1)], axis=1)]
-    for r in range(rings - 2):
-        a, b, c, d = vid(r, s), vid(r + 1, s), vid(r + 1, s + 1), vid(r, s + 1)
-        faces.append(np.stack([a, b, c], axis=1))
-        faces.append(np.stack([a, c, d], axis=1))
-    faces.append(np.stack([np.full(segs, south, dtype=np.int64), vid(rings - 2, s + 1), vid(rings - 2, s)], axis=1))
-    return ang, np.concatenate(faces)
+def _cube_sphere(n):
+    """Unit cube-sphere: each cube face is an n x n grid of quads split into two triangles, projected
+    onto the sphere.  6 n^2 + 2 vertices, 12 n^2 faces, every vertex of valence 4 to 6 (scanned meshes
+    have no high-valence poles; a lat-long sphere would put ~1000 slivers on each pole vertex)."""
+    g = np.arange(n + 1, dtype=np.int64)
+    U, V = np.meshgrid(g, g, indexing="ij")
+    U, V = U.ravel(), V.ravel()
+    Z, N = np.zeros_like(U), np.full_like(U, n)
+    # integer cube coordinates of each face's grid, oriented so that (du x dv) points outward
+    grids = [np.stack(c, axis=1) for c in ((N, U, V), (Z, V, U), (V, N, U), (U, Z, V), (U, V, N), (V, U, Z))]
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    ii, jj = ii.ravel(), jj.ravel()
+    a, b, c, d = ii * (n + 1) + jj, (ii + 1) * (n + 1) + jj, (ii + 1) * (n + 1) + jj + 1, ii * (n + 1) + jj + 1
+    quad = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)])
+    pts_i = np.concatenate(grids)
+    faces = np.concatenate([quad + k * (n + 1) ** 2 for k in range(6)])
+    # weld the shared edge / corner vertices of the six grids
+    key = (pts_i[:, 0] * (n + 1) + pts_i[:, 1]) * (n + 1) + pts_i[:, 2]
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    pts = pts_i[first].astype(np.float64) / n * 2.0 - 1.0
+    # equal-angle-ish warp before projection keeps triangle areas within ~2x of each other
+    pts = np.tan(pts * (np.pi / 4.0))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    return pts, inv[faces]
 
 
 def blob(n_faces, span=1.0, stretch=(1.0, 1.0, 1.0), seed=0, octaves=5, bumpiness=0.12, center=(0.0, 0.0, 0.0)):
     """A closed bumpy blob with exactly n_faces triangles: returns (vertices f32 [n,3], indices i32 [f,3])."""
     n_faces = int(n_faces)
-    if n_faces < 8:
-        raise ValueError("need at least 8 faces")
-    rings = max(3, int(np.sqrt(n_faces / 4.0)))
-    segs = max(3, (n_faces // (2 * (rings - 1))))
-    while 2 * segs * (rings - 1) > n_faces:
-        segs -= 1
-    ang, faces = _uv_sphere(rings, segs)
+    if n_faces < 12:
+        raise ValueError("need at least 12 faces")
+    n = max(1, int(np.sqrt(n_faces / 12.0)))
+    unit, faces = _cube_sphere(n)
     rs = np.random.RandomState(seed)
-    radius = np.ones(ang.shape[0])
+    radius = np.ones(unit.shape[0])
     for k in range(octaves):
-        f1, f2 = rs.randint(1, 4 + 3 * k, size=2)
-        p1, p2 = rs.uniform(0, 2 * np.pi, size=2)
+        freq = rs.randint(1, 4 + 3 * k, size=3).astype(np.float64)
+        axes = rs.standard_normal((3, 3))
+        axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+        phase = rs.uniform(0, 2 * np.pi, size=3)
         amp = bumpiness / (1.6 ** k)
-        radius += amp * np.sin(f1 * ang[:, 0] + p1) * np.cos(f2 * ang[:, 1] + p2) * np.sin(ang[:, 0])
-    st, ct = np.sin(ang[:, 0]), np.cos(ang[:, 0])
-    pts = np.stack([radius * st * np.cos(ang[:, 1]), radius * ct, radius * st * np.sin(ang[:, 1])], axis=1)
-    pts *= np.asarray(stretch, dtype=np.float64)
+        radius += amp * np.sin(freq[0] * np.pi * (unit @ axes[0]) + phase[0]) * np.cos(freq[1] * np.pi * (unit @ axes[1]) + phase[1]) \
+            * np.cos(freq[2] * np.pi * (unit @ axes[2]) + phase[2])
+    pts = unit * radius[:, None] * np.asarray(stretch, dtype=np.float64)
 
     # top up to the exact count: centroid splits (+2 faces, +1 vertex each), one edge split (+1) if odd
     missing = n_faces - faces.shape[0]
-    extra_pts, extra_faces = [], []
-    faces = faces.copy()
-    nv = pts.shape[0]
-    pick = rs.permutation(faces.shape[0])[: (missing + 1) // 2]
-    for t, fidx in enumerate(pick):
-        a, b, c = faces[fidx]
-        if missing - 2 * t >= 2:
-            extra_pts.append((pts[a] + pts[b] + pts[c]) / 3.0)
-            m = nv + len(extra_pts) - 1
-            faces[fidx] = (a, b, m)
-            extra_faces += [(b, c, m), (c, a, m)]
-        else:
-            extra_pts.append((pts[b] + pts[c]) / 2.0)
-            m = nv + len(extra_pts) - 1
-            faces[fidx] = (a, b, m)
-            extra_faces += [(a, m, c)]
-    if extra_pts:
-        pts = np.concatenate([pts, np.asarray(extra_pts)])
-        faces = np.concatenate([faces, np.asarray(extra_faces, dtype=np.int64)])
+    if missing > 0:
+        n_tri_split, odd = missing // 2, missing % 2
+        pick = rs.permutation(faces.shape[0])[: n_tri_split + odd]
+        nv = pts.shape[0]
+        faces = faces.copy()
+        tri = faces[pick[:n_tri_split]]
+        cen = pts[tri].mean(axis=1)
+        m = nv + np.arange(n_tri_split)
+        extra = [np.stack([tri[:, 1], tri[:, 2], m], axis=1), np.stack([tri[:, 2], tri[:, 0], m], axis=1)]
+        faces[pick[:n_tri_split], 2] = m
+        new_pts = [cen]
+        if odd:
+            fa, fb, fc = faces[pick[-1]]
+            new_pts.append(((pts[fb] + pts[fc]) / 2.0)[None, :])
+            mid = nv + n_tri_split
+            faces[pick[-1]] = (fa, fb, mid)
+            extra.append(np.array([[fa, mid, fc]]))
+        pts = np.concatenate([pts] + new_pts)
+        faces = np.concatenate([faces] + extra)
     assert faces.shape[0] == n_faces, (faces.shape[0], n_faces)
 
     ext = pts.max(axis=0) - pts.min(axis=0)

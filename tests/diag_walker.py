@@ -1,0 +1,27 @@
+"""Walker diagnostics on the bench workload (profiling helper, not a test): per-phase lane utilisation."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import ray_tracer_amd as rt
+
+model = sys.argv[1] if len(sys.argv) > 1 else "dragon"
+W, H, spp = 1920, 1080, 4
+cfg = rt.meshgen.STANFORD[model]
+v, i = rt.meshgen.stanford_standin(model)
+light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+mesh = rt.TriangleMesh((v, i), rt.ColorInformation((0.9, 0.9, 0.9)), True)
+for lm, name in ((rt.LightingModel(), "primary only"), (rt.PhongLightingModel(light, [mesh]), "primary+shadow")):
+    scene = rt.Scene([mesh], light, cfg["orientation"], lm, cfg["fov"])
+    cam = rt.Camera(scene, spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    frame = rt._abi.Frame(rgb.data_ptr(), None, None, None, None)
+    cam.render_device(frame, collect_stats=True)
+    torch.cuda.synchronize()
+    d = cam.debug_counters()
+    names = ["primary", "shadow", "secondary", "box", "tri", "hits", "node_lane", "node_wave", "leaf_lane", "leaf_wave", "outer", "refill"]
+    print(name, dict(zip(names, d)))
+    print("  steals %d" % d[12])
+    print("  node-phase lane util %.3f  leaf-phase lane util %.3f  node trips/outer %.1f leaf trips/outer %.1f" % (
+        d[6] / max(64.0 * d[7], 1), d[8] / max(64.0 * d[9], 1), d[7] / max(d[10], 1), d[9] / max(d[10], 1)))
+    scene.close()
