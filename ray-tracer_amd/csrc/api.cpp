@@ -289,7 +289,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t str
    const size_t slots_per_micro = (size_t) 64 * (size_t) p.multi_samples;
    const long long micro_per_pass = (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
    const long long first_pass = std::min(n_micro, micro_per_pass);
-   if (int rc = ensure_scratch(s, (size_t) first_pass * slots_per_micro, s->has_mirror)) return rc;
+   if (int rc = ensure_scratch(s, (size_t) ((first_pass + N_BANDS - 1) / N_BANDS) * N_BANDS * slots_per_micro, s->has_mirror)) return rc;
    const FrameScratch &fs = s->scratch;
    p.samples = fs.samples;
    p.rays0 = fs.rays0;
@@ -309,29 +309,32 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t str
 
    for (long long m0 = 0; m0 < n_micro; m0 += micro_per_pass) {
       const long long m1 = std::min(n_micro, m0 + micro_per_pass);
-      const unsigned long long slots = (unsigned long long) (m1 - m0) * slots_per_micro;
       p.micro_begin = (int32_t) m0;
       p.micro_end = (int32_t) m1;
+      p.band_cap = (uint32_t) ((((unsigned long long) (m1 - m0) + N_BANDS - 1) / N_BANDS) * slots_per_micro);
+      const unsigned long long slots = (unsigned long long) p.band_cap * N_BANDS;   // queue capacity of the pass
       HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
       HIP_TRY(launch_generate(p, stream));
       int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
       auto next_cursor = [&]() -> int { return CNT_CURSOR0 + 8 * (cursor_set++); };
-      HIP_TRY(launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, next_cursor(), slots, s->n_cus, p.stats ? 2 : 0, stream));
+      HIP_TRY(launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, next_cursor(), p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, stream));
       HIP_TRY(launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream));
       if (s->has_mirror) {
          // mirror bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
          int cur = 0;
          for (int bounce = 0; bounce <= p.max_mirror_bounces; bounce++) {
-            uint32_t n_sec = 0;
-            HIP_TRY(hipMemcpyAsync(&n_sec, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), sizeof(n_sec), hipMemcpyDeviceToHost, stream));
+            uint32_t n_band[N_BANDS];
+            HIP_TRY(hipMemcpyAsync(n_band, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), sizeof(n_band), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            unsigned long long n_sec = 0;
+            for (uint32_t nb : n_band) n_sec += nb;
             if (n_sec == 0) break;
             const int cur_cnt = cur == 0 ? CNT_SEC_A : CNT_SEC_B, nxt_cnt = cur == 0 ? CNT_SEC_B : CNT_SEC_A;
             if (cursor_set >= CNT_CURSOR_SETS - 1) cursor_set = 1;   // keep the last set for the shadow launch
             const int cw = next_cursor();
             HIP_TRY(hipMemsetAsync(p.counters + cw, 0, 8 * sizeof(uint32_t), stream));
-            HIP_TRY(hipMemsetAsync(p.counters + nxt_cnt, 0, sizeof(uint32_t), stream));
-            HIP_TRY(launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, n_sec, s->n_cus, p.stats ? 1 : 0, stream));
+            HIP_TRY(hipMemsetAsync(p.counters + nxt_cnt, 0, N_BANDS * sizeof(uint32_t), stream));
+            HIP_TRY(launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, p.band_cap, n_sec, s->n_cus, p.stats ? 1 : 0, stream));
             HIP_TRY(launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream));
             cur ^= 1;
          }
@@ -746,6 +749,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    a.sc.far_plane = settings->far_plane;
    a.sc.scene_abs_max = scene->abs_max;
    a.n = (uint32_t) n;
+   a.band_cap = (uint32_t) ((n + N_BANDS - 1) / N_BANDS);
    a.origins = (const float *) buf.p[0];
    a.dirs = (const float *) buf.p[1];
    a.rays = (float *) buf.p[2];
@@ -759,7 +763,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    a.out_normal = (float *) buf.p[9];
    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, CNT_WORDS * sizeof(uint32_t), nullptr));
    HIP_TRY(launch_batch_pack(a, nullptr));
-   HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, n, scene->n_cus, 0, nullptr));
+   HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, a.band_cap, n, scene->n_cus, 0, nullptr));
    HIP_TRY(launch_batch_unpack(a, nullptr));
    HIP_TRY(hipStreamSynchronize(nullptr));
    if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[5], sizes[5], hipMemcpyDeviceToHost));

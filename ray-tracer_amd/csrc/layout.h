@@ -79,14 +79,21 @@ struct SceneArgs {
    float scene_abs_max;   // max |coordinate| of the scene bounds (prune margin)
 };
 
+// Every queue is N_BANDS sub-queues of band_cap slots each: the pass's 8x8 pixel groups are cut into
+// N_BANDS consecutive runs (bands of the image) and a ray, its shadow ray and its bounce rays all stay
+// in their pixel's band.  One counter per sub-queue keeps the appends off a single hot address, and a
+// walker workgroup starts on band blockIdx % N_BANDS (workgroups b and b + 8 share an XCD, hence an
+// L2), so each L2 mostly serves one band's geometry.
+constexpr int N_BANDS = 8;
+
 // counters[] slots
 enum {
-   CNT_Q0 = 0,        // primary queue size
-   CNT_SHADOW = 1,    // shadow list size
-   CNT_SEC_A = 2,     // secondary queues (ping-pong)
-   CNT_SEC_B = 3,
-   CNT_STATS = 16,    // 16 x 64-bit stats counters (u32 pairs): 6 public + walker diagnostics
-   CNT_CURSOR0 = 64,  // work cursors of the persistent launches: 8 (one per queue range) per launch
+   CNT_Q0 = 0,        // primary queue sizes        [N_BANDS]
+   CNT_SHADOW = 8,    // shadow list sizes          [N_BANDS]
+   CNT_SEC_A = 16,    // secondary queues (ping-pong) [N_BANDS] each
+   CNT_SEC_B = 24,
+   CNT_STATS = 32,    // 16 x 64-bit stats counters (u32 pairs): 6 public + walker diagnostics
+   CNT_CURSOR0 = 64,  // work cursors of the persistent launches: N_BANDS per launch
    CNT_CURSOR_SETS = 8,
    CNT_WORDS = 64 + 8 * 8
 };
@@ -109,6 +116,7 @@ struct FrameArgs {
    // tiles: this pass covers 8x8 pixel groups [micro_begin, micro_end) of the rank's enumeration
    int32_t tile_size, tile_rank, tile_world, tiles_x, tiles_y, micro_per_tile;
    int32_t micro_begin, micro_end;
+   uint32_t band_cap;   // slots per band sub-queue: ceil(groups in pass / N_BANDS) * 64 * multi_samples
    // scratch
    float *samples;      // float4[cap]
    float *rays0;        // 2 x float4[cap]   primary queue
@@ -131,6 +139,7 @@ struct FrameArgs {
 struct TraceBatchArgs {   // mi355rt_trace_rays
    SceneArgs sc;
    uint32_t n;
+   uint32_t band_cap;             // ceil(n / N_BANDS)
    const float *origins, *dirs;   // n*3 each (user layout)
    float *rays;                   // 2 x float4[n]
    float *hits;                   // 2 x float4[n]

@@ -26,6 +26,8 @@
 // order-independently on (distance, first-slot-of-leaf).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 #include "layout.h"
 
@@ -430,11 +432,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs
    const int lane = threadIdx.x & 63;
    const long long wave = (long long) blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6);
    const int ms = p.multi_samples;
-   const long long n_waves = (long long) (p.micro_end - p.micro_begin) * ms;
-   if (wave >= n_waves) return;
-   const int local_micro = (int) (wave / ms);
+   const int n_micro = p.micro_end - p.micro_begin;
+   const int per_band = (n_micro + N_BANDS - 1) / N_BANDS;
+   if (wave >= (long long) per_band * N_BANDS * ms) return;
+   // consecutive workgroups take groups from different bands: they run at the same time and would
+   // otherwise all append to one sub-queue's counter
+   const int unit = (int) (wave / ms);
+   const int local_micro = (unit % N_BANDS) * per_band + unit / N_BANDS;
+   if (local_micro >= n_micro) return;
    const int j = (int) (wave % ms);
-   const unsigned slot = (unsigned) (wave * 64 + lane);
+   const unsigned slot = ((unsigned) local_micro * (unsigned) ms + (unsigned) j) * 64u + (unsigned) lane;
    int px, py;
    const bool active = micro_pixel(p, p.micro_begin + local_micro, lane, px, py);
    const long long pix = (long long) py * p.width + px;
@@ -469,7 +476,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs
       ((float4 *) p.samples)[slot] = make_float4(p.light_ambient[0], p.light_ambient[1], p.light_ambient[2], 0.0f);
       if (j == 0) write_miss_outputs(p, pix);
    }
-   const unsigned idx = queue_push(p.counters + CNT_Q0, push);
+   // the pass's 8x8 groups are cut into 8 bands (image order); each band has its own sub-queue
+   const int band = local_micro / per_band;
+   const unsigned idx = (unsigned) band * p.band_cap + queue_push(p.counters + CNT_Q0 + band, push);
    if (push) store_ray(p.rays0, idx, o, d, slot, -1);
    if (p.stats) {
       add_stat(p.counters, ST_PRIMARY, active ? 1u : 0u);
@@ -496,7 +505,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs
 // when its own is drained.  Queue order follows image order, so each L2 mostly sees one band of the
 // image.  Placement only affects speed: every ray is claimed exactly once whatever runs where.
 enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2 };
-constexpr int REFILL_MIN = 16;   // refill once this many lanes are idle (or all of them)
 
 struct WalkArgs {
    SceneArgs sc;
@@ -508,13 +516,16 @@ struct WalkArgs {
    const uint32_t *shadow;
    float light[3];
    uint32_t *counters;
-   int32_t count_index, cursor_index;
+   int32_t count_index, cursor_index;   // first of N_BANDS counters / cursors
+   uint32_t band_cap;                   // slots per band sub-queue
    int32_t stats;
+   int32_t refill_min;   // refill once this many lanes are idle (or all of them)
+   int32_t steal_min;    // while the queue still has rays: steal once this many lanes are idle
+   int32_t both_min;     // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
 };
 
 // lane roles
 enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
-constexpr int STEAL_MIN = 8;        // while the queue still has rays: steal once this many lanes are idle
 constexpr bool FETCH_DMA = false;   // record fetch through LDS (global_load_lds) instead of per-lane loads
 
 template <bool STATS, int MODE>
@@ -529,7 +540,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
    volatile int *list = s_list + wave_base;
    float4 *stage = s_stage + (FETCH_DMA ? 4 * wave_base : 0);
    const unsigned long long lanes_below = (1ull << lane) - 1ull;
-   const unsigned count = a.counters[a.count_index];
    uint32_t *cursors = a.counters + a.cursor_index;
    const float4 *__restrict__ nodes = (const float4 *) a.sc.nodes;
    const float4 *__restrict__ tris = (const float4 *) a.sc.tris;
@@ -538,7 +548,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
    const int n_objs = a.sc.n_objs;
 
    // wave-uniform
-   const int home = (int) (blockIdx.x & 7u);
+   const int home = (int) (blockIdx.x % (unsigned) N_BANDS);
    int attempt = 0;
    bool exhausted = false;
    // per lane
@@ -557,6 +567,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
    int s = 0, leaf0 = 0;   // current slot / first slot of the current leaf (valid while cur < 0)
    unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0;
    unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
+   const unsigned long long t_begin = STATS ? wall_clock64() : 0ull;   // 100 MHz
+   unsigned long long t_exhausted = 0ull;
 
    for (;;) {
       if (STATS && lane == 0) d_outer++;
@@ -655,15 +667,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
 
          // ---- (3) idle lanes take new rays from the queue
          const unsigned long long idle = __ballot(role == ROLE_IDLE);
-         if (idle != 0ull && !exhausted && (__popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
+         if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             const unsigned want_n = (unsigned) __popcll(idle);
             if (STATS && lane == 0) d_refill++;
             unsigned base = 0, limit = 0;
             bool got = false;
-            while (attempt < 8) {
-               const unsigned rg = (unsigned) (home + attempt) & 7u;
-               const unsigned lo = (unsigned) ((unsigned long long) count * rg / 8ull);
-               const unsigned hi = (unsigned) ((unsigned long long) count * (rg + 1u) / 8ull);
+            while (attempt < N_BANDS) {
+               const unsigned rg = (unsigned) (home + attempt) % (unsigned) N_BANDS;
+               const unsigned lo = rg * a.band_cap;
+               const unsigned hi = lo + a.counters[a.count_index + rg];
                unsigned b = 0;
                if (lane == 0) b = atomicAdd(cursors + rg, want_n);
                b = (unsigned) __builtin_amdgcn_readfirstlane((int) b);
@@ -677,6 +689,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
             }
             if (!got) {
                exhausted = true;
+               if (STATS) t_exhausted = wall_clock64();
             } else if (role == ROLE_IDLE) {
                const unsigned my = base + (unsigned) __popcll(idle & lanes_below);
                if (my < limit) {
@@ -717,7 +730,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
          // subtree cannot change the result: the fold is order independent (see the header comment).
          const unsigned long long thieves = __ballot(role == ROLE_IDLE);
          const unsigned long long victims = __ballot(role != ROLE_IDLE && sp > bot);
-         if (thieves != 0ull && victims != 0ull && (exhausted || __popcll(thieves) >= STEAL_MIN)) {
+         if (thieves != 0ull && victims != 0ull && (exhausted || __popcll(thieves) >= a.steal_min)) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
             const int v_rank = __popcll(victims & lanes_below), t_rank = __popcll(thieves & lanes_below);
             const bool is_victim = ((victims >> lane) & 1ull) != 0ull && v_rank < n_pairs;
@@ -769,9 +782,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
          }
       }
 
-      // ---- one step per lane: an internal node (C) or one face of a leaf (D)
-      const bool is_node = (unsigned) cur < (unsigned) STACK_EMPTY;
-      const bool is_leaf = cur < 0;
+      // ---- one step per lane: an internal node (C) or one face of a leaf (D).  A trip that ran both
+      // paths for a handful of lanes each would spend most of its issue slots on masked-off lanes, so
+      // the minority state sits a trip out unless it is populous too (it becomes the majority soon).
+      const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
+      const bool in_leaf = cur < 0;
+      const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
+      const bool both = n_node >= a.both_min && n_leaf >= a.both_min;
+      const bool is_node = in_node && (both || n_node >= n_leaf);
+      const bool is_leaf = in_leaf && (both || n_leaf > n_node);
       float4 na, nb, nc, A, B, C;
       int4 nd;
       if (FETCH_DMA) {
@@ -899,6 +918,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
       add_stat(a.counters, ST_OUTER_WAVE, d_outer);
       add_stat(a.counters, ST_REFILL, d_refill);
       add_stat(a.counters, 12, d_steal);
+      if (lane == 0) {
+         const unsigned long long t_end = wall_clock64();
+         unsigned long long *st = (unsigned long long *) (a.counters + CNT_STATS);
+         atomicMax(st + 13, t_end - t_begin);                               // longest wave lifetime
+         atomicAdd(st + 14, t_end - t_begin);                               // sum of wave lifetimes
+         atomicAdd(st + 15, t_exhausted ? t_end - t_exhausted : 0ull);      // sum of time spent after the queue ran dry
+      }
    }
 }
 
@@ -910,11 +936,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
                                                               const int32_t *hit_obj, int count_index, float *rays_next,
                                                               int next_count_index)
 {
-   const unsigned count = p.counters[count_index];
    unsigned n_sec = 0;
-   for (unsigned base = blockIdx.x * BLOCK_THREADS; base < count; base += gridDim.x * BLOCK_THREADS) {
-   const unsigned i = base + threadIdx.x;
-   const bool active = i < count;
+   {
+   const int band = (int) (blockIdx.x % (unsigned) N_BANDS);   // a workgroup serves one band (grid is a multiple of N_BANDS)
+   const unsigned count = p.counters[count_index + band];
+   for (unsigned base = (blockIdx.x / N_BANDS) * BLOCK_THREADS; base < count; base += (gridDim.x / N_BANDS) * BLOCK_THREADS) {
+   const bool active = base + threadIdx.x < count;
+   const unsigned i = (unsigned) band * p.band_cap + base + threadIdx.x;
    bool push_shadow = false, push_sec = false;
    unsigned path = 0;
    V3 sec_o = mk3(0, 0, 0), sec_d = mk3(0, 0, -1);
@@ -996,11 +1024,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
          }
       }
    }
-   const unsigned si = queue_push(p.counters + CNT_SHADOW, push_shadow);
+   // a path's shadow ray and bounce ray stay in the path's band
+   const unsigned si = (unsigned) band * p.band_cap + queue_push(p.counters + CNT_SHADOW + band, push_shadow);
    if (push_shadow) p.shadow[si] = path;
    if (rays_next) {
-      const unsigned qi = queue_push(p.counters + next_count_index, push_sec);
+      const unsigned qi = (unsigned) band * p.band_cap + queue_push(p.counters + next_count_index + band, push_sec);
       if (push_sec) store_ray(rays_next, qi, sec_o, sec_d, path, sec_aux);
+   }
    }
    }
    if (p.stats) add_stat(p.counters, ST_SECONDARY, n_sec);
@@ -1009,9 +1039,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
 // ---------------------------------------------------------------- Phong combine
 __global__ __launch_bounds__(BLOCK_THREADS) void phong_kernel(const FrameArgs p)
 {
-   const unsigned count = p.counters[CNT_SHADOW];
-   for (unsigned i = blockIdx.x * BLOCK_THREADS + threadIdx.x; i < count; i += gridDim.x * BLOCK_THREADS) {
-   const unsigned path = p.shadow[i];
+   {
+   const int band = (int) (blockIdx.x % (unsigned) N_BANDS);
+   const unsigned count = p.counters[CNT_SHADOW + band];
+   for (unsigned i = (blockIdx.x / N_BANDS) * BLOCK_THREADS + threadIdx.x; i < count; i += (gridDim.x / N_BANDS) * BLOCK_THREADS) {
+   const unsigned path = p.shadow[(unsigned) band * p.band_cap + i];
    const float4 *q = (const float4 *) p.rays0 + 2 * (size_t) path;
    const float4 r0 = q[0], r1 = q[1];
    const float4 *hq = (const float4 *) p.hits0 + 2 * (size_t) path;
@@ -1025,6 +1057,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void phong_kernel(const FrameArgs p)
                  mk3(p.light_origin[0], p.light_origin[1], p.light_origin[2]), mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z),
                  mk3(r1.x, r1.y, r1.z), m4.w != 0.0f, out);
    ((float4 *) p.samples)[__float_as_uint(r0.w)] = make_float4(out[0], out[1], out[2], 0.0f);
+   }
    }
 }
 
@@ -1071,7 +1104,10 @@ __global__ void batch_pack_kernel(const TraceBatchArgs a)
    const V3 o = mk3(a.origins[3 * (size_t) i], a.origins[3 * (size_t) i + 1], a.origins[3 * (size_t) i + 2]);
    const V3 d = normalize3(mk3(a.dirs[3 * (size_t) i], a.dirs[3 * (size_t) i + 1], a.dirs[3 * (size_t) i + 2]));   // Ray ctor
    store_ray(a.rays, i, o, d, i, -1);
-   if (i == 0) a.counters[CNT_Q0] = a.n;
+   if (i < (unsigned) N_BANDS) {   // band b holds rays [b * band_cap, min(n, (b + 1) * band_cap))
+      const unsigned long long lo = (unsigned long long) i * a.band_cap;
+      a.counters[CNT_Q0 + i] = lo >= a.n ? 0u : (unsigned) ((a.n - lo) < a.band_cap ? (a.n - lo) : a.band_cap);
+   }
 }
 
 __global__ void batch_unpack_kernel(const TraceBatchArgs a)
@@ -1115,9 +1151,15 @@ namespace {
 unsigned blocks_for(unsigned long long n) { return (unsigned) ((n + BLOCK_THREADS - 1) / BLOCK_THREADS); }
 
 // persistent grids: enough resident waves to fill the chip, never more than the work can use
+int tunable(const char *name, int fallback)
+{
+   const char *v = getenv(name);
+   return v && *v ? atoi(v) : fallback;
+}
+
 unsigned persistent_grid(int n_cus, unsigned long long max_items)
 {
-   const unsigned long long want = (unsigned long long) n_cus * (FETCH_DMA ? 4ull : 6ull);   // blocks of 4 waves per CU (LDS: 25 KB, 41 KB with staging)
+   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) tunable("MI355RT_BLOCKS_PER_CU", FETCH_DMA ? 4 : 6);   // blocks of 4 waves per CU (LDS: 25 KB, 41 KB with staging)
    const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
    return (unsigned) (need < want ? (need ? need : 1ull) : want);
 }
@@ -1127,7 +1169,8 @@ unsigned bounded_grid(int n_cus, unsigned long long max_items)
 {
    const unsigned long long want = (unsigned long long) n_cus * 8ull;
    const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
-   return (unsigned) (need < want ? (need ? need : 1ull) : want);
+   const unsigned long long g = need < want ? (need ? need : 1ull) : want;
+   return (unsigned) ((g + N_BANDS - 1) / N_BANDS * N_BANDS);   // each workgroup serves one band
 }
 
 }   // namespace
@@ -1145,7 +1188,7 @@ hipError_t launch_walk(const WalkArgs &a, unsigned grid, bool stats, hipStream_t
 }   // namespace
 
 hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
-                        int cursor_index, unsigned long long max_items, int n_cus, int stats, hipStream_t stream)
+                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, hipStream_t stream)
 {
    WalkArgs a;
    a.sc = sc;
@@ -1159,14 +1202,19 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.counters = counters;
    a.count_index = count_index;
    a.cursor_index = cursor_index;
+   a.band_cap = band_cap;
    a.stats = stats;
+   a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
+   a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
+   a.both_min = tunable("MI355RT_BOTH_MIN", 20);
    return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats != 0, stream);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
 {
-   const unsigned long long waves = (unsigned long long) (p.micro_end - p.micro_begin) * (unsigned long long) p.multi_samples;
-   if (!waves) return hipSuccess;
+   const unsigned long long n_micro = (unsigned long long) (p.micro_end - p.micro_begin);
+   const unsigned long long waves = (n_micro + N_BANDS - 1) / N_BANDS * N_BANDS * (unsigned long long) p.multi_samples;
+   if (!n_micro) return hipSuccess;
    hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(waves * 64)), dim3(BLOCK_THREADS), 0, stream, p);
    return hipGetLastError();
 }
@@ -1201,7 +1249,11 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.counters = p.counters;
    a.count_index = CNT_SHADOW;
    a.cursor_index = cursor_index;
+   a.band_cap = p.band_cap;
    a.stats = p.stats;
+   a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
+   a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
+   a.both_min = tunable("MI355RT_BOTH_MIN", 20);
    const unsigned grid = persistent_grid(n_cus, max_items);
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, p.stats != 0, stream);
    return launch_walk<MODE_SHADOW>(a, grid, p.stats != 0, stream);
