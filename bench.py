@@ -9,7 +9,9 @@ replicated, and the step ends with ONE gather of the tiles to rank 0 over RCCL (
 the frame is fixed).  Rays are counted by the kernel, not assumed.
 
 Prints ONE JSON line on rank 0 (see the repository's bench contract) with two extra objects:
-  roofline     -- algorithmic bytes of the render kernel per launch / its HIP-event duration vs 8 TB/s
+  roofline     -- the dominant kernel (the primary-ray walker): its algorithmic bytes per launch / its
+                  average launch duration, from HIP events the library records around every kernel on
+                  the stream it launches on, over the timed region, vs 8 TB/s
   cpu_baseline -- the oracle (C restatement of the reference's algorithm, reference visit order) timed
                   on this host's cores on a bounded sample of the same frame.
 """
@@ -46,7 +48,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU work for the baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,14 +84,15 @@ def main():
     sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev)
     stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream
 
-    def step(stats=False):
+    def step(stats=False, times=False):
         cam.render_device(frame, stream=stream, tile_rank=rank, tile_world=world, tile_size=tiles.DEFAULT_TILE,
-                          collect_stats=stats)
+                          collect_stats=stats, collect_times=times)
 
     # counted, not assumed: one instrumented frame
     step(stats=True)
     torch.cuda.synchronize()
     st = cam.frame_stats()
+    kcounts = cam.kernel_profile(reset=True)   # per-walker counts of that frame
     counts = torch.tensor([st["primary_rays"], st["shadow_rays"], st["secondary_rays"], st["box_tests"], st["tri_tests"],
                            st["hits"]], dtype=torch.float64, device=dev)
     local_counts = counts.clone()
@@ -99,8 +102,10 @@ def main():
     rays_per_frame = primary + shadow + secondary
 
     for _ in range(args.warmup):
-        step()
+        step(times=True)
         sharder.gather(rgb, hit_w, hit_id)
+    torch.cuda.synchronize()
+    cam.kernel_profile(reset=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -109,7 +114,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        step()
+        step(times=True)
         ev[k][1].record()
         sharder.gather(rgb, hit_w, hit_id)
     torch.cuda.synchronize()
@@ -117,7 +122,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # all kernels of one frame, this rank
+    kprof = cam.kernel_profile()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -130,11 +136,22 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant (only) kernel, this rank's launch
+    # roofline of the dominant kernel, this rank's launches over the timed region
+    kernels = {name: {"ms_per_launch": round(v["ms"] / v["launches"], 4), "launches_per_frame": v["launches"] / args.steps,
+                      "ms_per_frame": round(v["ms"] / args.steps, 4)}
+               for name, v in kprof.items() if v["launches"]}
+    dom = max(kernels, key=lambda n: kernels[n]["ms_per_frame"])
     lp, ls, lsec, lb, lt, lh = [float(x) for x in local_counts.tolist()]
     own_pixels = float(sharder.my_pix.ge(0).sum().item())
-    algo_bytes = BYTES_PER_BOX_TEST * lb + BYTES_PER_TRI_TEST * lt + BYTES_PER_HIT * lh + BYTES_PER_PIXEL * own_pixels
-    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    frame_bytes = BYTES_PER_BOX_TEST * lb + BYTES_PER_TRI_TEST * lt + BYTES_PER_HIT * lh + BYTES_PER_PIXEL * own_pixels
+    kc = kcounts[dom]
+    n_launch = max(kernels[dom]["launches_per_frame"], 1.0)
+    # SURVEY.md 8(d) per-unit figures x the units one launch of that kernel processes (counted by the kernel itself
+    # in the instrumented frame): child boxes tested, triangle slots tested, final hits whose normals are fetched
+    dom_hits = lh if dom == "walk_primary" else 0.0
+    algo_bytes = (BYTES_PER_BOX_TEST * kc["box_tests"] + BYTES_PER_TRI_TEST * kc["tri_tests"] + BYTES_PER_HIT * dom_hits) / n_launch
+    dom_ms = kernels[dom]["ms_per_launch"]
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -142,15 +159,20 @@ def main():
             with open(tpath) as f:
                 tj = json.load(f)
             key = "%s_%dx%d_%dspp_n%d" % (args.model, W, H, args.spp, world)
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            traffic = tj.get(key, {}).get(dom, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    dom_rays = max(kc["rays"] / n_launch, 1.0)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "render_kernel",
-                "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": algo_bytes,
-                "bytes_per_ray": round(algo_bytes / max(lp + ls + lsec, 1.0), 1),
-                "box_tests_per_ray": round(lb / max(lp + ls + lsec, 1.0), 2),
-                "tri_tests_per_ray": round(lt / max(lp + ls + lsec, 1.0), 2)}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": {"walk_primary": "walk_kernel<false,MODE_CLOSEST> (primary rays)",
+                           "walk_shadow": "walk_kernel<false,MODE_SHADOW_ANY> (shadow rays)"}.get(dom, dom),
+                "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "rays_per_launch": dom_rays, "bytes_per_ray": round(algo_bytes / dom_rays, 1),
+                "box_tests_per_ray": round(kc["box_tests"] / n_launch / dom_rays, 2),
+                "tri_tests_per_ray": round(kc["tri_tests"] / n_launch / dom_rays, 2),
+                "frame": {"gpu_ms": round(frame_ms, 4), "algorithmic_bytes": frame_bytes,
+                          "achieved_GBs": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 2), "kernels": kernels}}
 
     cpu = None
     if not args.no_cpu_baseline:
@@ -186,7 +208,8 @@ def cpu_baseline(args, verts, idx, cfg, light):
     ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, args.width, args.height)
     ost = oracle.settings(epsilon=osc.epsilon(), ms=args.spp, lighting=1, seed=2024, light_origin=light.origin,
                           light_emission=light.emission, light_ambient=light.ambient)
-    # probe at a sparse stride, then choose the stride for the timed sample
+    # probe at a sparse stride, then size the timed sample to about --cpu-seconds of wall time on these cores:
+    # a strided subset of the frame when the whole frame would take longer, else the whole frame, repeated
     stride = 257
     t0 = time.perf_counter()
     o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
@@ -195,16 +218,22 @@ def cpu_baseline(args, verts, idx, cfg, light):
     stride = max(1, int(np.ceil(full_s / args.cpu_seconds)))
     if stride > 1 and stride % 2 == 0:
         stride += 1   # odd strides walk every column of an even-width image
+    rays = 0
+    repeats = 0
     t0 = time.perf_counter()
-    o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
-    dt = time.perf_counter() - t0
-    s = o["stats"]
-    rays = s["primary_rays"] + s["shadow_rays"] + s["secondary_rays"]
+    while True:   # at least one pass over the sample, then more until about --cpu-seconds have gone
+        o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
+        s = o["stats"]
+        rays += s["primary_rays"] + s["shadow_rays"] + s["secondary_rays"]
+        repeats += 1
+        dt = time.perf_counter() - t0
+        if dt * (repeats + 1) / repeats > args.cpu_seconds or repeats >= 64:
+            break
     osc.close()
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "every %d-th pixel of the same %dx%d frame, %d spp + shadow rays (%d rays, %.1f s); "
+            "sample": "every %d-th pixel of the same %dx%d frame, %d spp + shadow rays, rendered %d time(s) (%d rays, %.1f s); "
                       "C restatement of the Java algorithm in reference visit order, %d pthreads"
-                      % (stride, args.width, args.height, args.spp, rays, dt, cores),
+                      % (stride, args.width, args.height, args.spp, repeats, rays, dt, cores),
             "java_present": bool(any(os.path.exists(os.path.join(p, "java")) for p in os.environ.get("PATH", "").split(":")))}
 
 

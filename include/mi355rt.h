@@ -82,13 +82,37 @@ typedef struct {
    float light_origin[3], light_emission[3], light_ambient[3]; /* lighting/Light.java:7-16 */
    int32_t tile_size;           /* image-tile sharding: square tiles of this many pixels (multiple of 8; 0 = 16) */
    int32_t tile_rank, tile_world; /* this process renders tiles t with t % tile_world == tile_rank */
-   int32_t collect_stats;       /* non-zero: count rays / box tests / triangle tests (slower; see mi355rt_frame_stats) */
+   int32_t collect_stats;       /* bit mask: MI355RT_COLLECT_COUNTS (count rays / box tests / triangle tests; slower; see
+                                 * mi355rt_frame_stats), MI355RT_COLLECT_TIMES (HIP events around every kernel; see
+                                 * mi355rt_kernel_profile) */
 } mi355rt_settings;
 
 typedef struct {
    uint64_t primary_rays, shadow_rays, secondary_rays;
    uint64_t box_tests, tri_tests, hits;
 } mi355rt_stats;
+
+#define MI355RT_COLLECT_COUNTS 1
+#define MI355RT_COLLECT_TIMES 2
+
+/* the kernels of one frame (the wavefront pipeline of DESIGN.md), as indices into mi355rt_kernel_times */
+enum {
+   MI355RT_K_GENERATE = 0,       /* primary rays: Camera.createImage / RenderThread.run ray set-up */
+   MI355RT_K_WALK_PRIMARY = 1,   /* closest hit of the primary rays (Camera.getClosestIntersection) */
+   MI355RT_K_SHADE = 2,          /* material colour, mirror bounce generation, shadow list */
+   MI355RT_K_WALK_SECONDARY = 3, /* closest hit of mirror-bounce rays */
+   MI355RT_K_WALK_SHADOW = 4,    /* RTStatics.shadowIntersects */
+   MI355RT_K_PHONG = 5,          /* PhongLightingModel.getPixelColor */
+   MI355RT_K_RESOLVE = 6,        /* RenderThread's average over the samples, pixel write */
+   MI355RT_N_KERNELS = 8
+};
+
+typedef struct {
+   double ms[MI355RT_N_KERNELS];          /* summed HIP-event time per kernel since the last reset */
+   uint64_t launches[MI355RT_N_KERNELS];
+   /* of the most recent MI355RT_COLLECT_COUNTS frame, per walker kernel (other entries 0) */
+   uint64_t rays[MI355RT_N_KERNELS], box_tests[MI355RT_N_KERNELS], tri_tests[MI355RT_N_KERNELS];
+} mi355rt_kernel_times;
 
 /* device-resident frame outputs; any pointer may be NULL.  Pixel p = y*width + x (row-major);
  * Camera.pixels[x][y] is the transpose. */
@@ -150,6 +174,12 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
 /* Counters of the most recent render on this scene that ran with settings.collect_stats != 0
  * (blocking: synchronises the scene's device). */
 int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out);
+
+/* Per-kernel HIP-event times of the renders that ran with MI355RT_COLLECT_TIMES since the last reset,
+ * and the per-kernel counts of the most recent MI355RT_COLLECT_COUNTS render (blocking: waits for the
+ * pending events).  reset != 0 clears the times afterwards.  No counterpart in the reference: it is
+ * what bench.py's roofline line is computed from. */
+int mi355rt_kernel_profile(mi355rt_scene *scene, mi355rt_kernel_times *out, int reset);
 
 /* Camera.getClosestIntersection(null, origin, direction, null, 0) for a batch of rays
  * (Camera.java:193-215): host buffers, n*3 origins / directions in; any output may be NULL. */

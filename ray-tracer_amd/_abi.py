@@ -56,6 +56,16 @@ class Stats(C.Structure):
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64)]
 
 
+COLLECT_COUNTS, COLLECT_TIMES = 1, 2
+K_GENERATE, K_WALK_PRIMARY, K_SHADE, K_WALK_SECONDARY, K_WALK_SHADOW, K_PHONG, K_RESOLVE, N_KERNELS = 0, 1, 2, 3, 4, 5, 6, 8
+KERNEL_NAMES = ("generate", "walk_primary", "shade", "walk_secondary", "walk_shadow", "phong", "resolve")
+
+
+class KernelProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * N_KERNELS), ("launches", C.c_uint64 * N_KERNELS), ("rays", C.c_uint64 * N_KERNELS),
+                ("box_tests", C.c_uint64 * N_KERNELS), ("tri_tests", C.c_uint64 * N_KERNELS)]
+
+
 class Frame(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("argb8", C.c_void_p), ("hit_id", C.c_void_p),
                 ("hit_obj", C.c_void_p), ("hit_w", C.c_void_p)]
@@ -75,6 +85,7 @@ PROTOTYPES = {
     "mi355rt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), c_float_p, c_int32_p, c_float_p]),
     "mi355rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
     "mi355rt_frame_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "mi355rt_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile), C.c_int]),
     "mi355rt_trace_rays": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_uint64, c_float_p, c_float_p, c_int32_p,
                                      c_int32_p, c_float_p, c_float_p, c_float_p]),
     "mi355rt_debug_arith": (C.c_int, [C.c_uint64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),

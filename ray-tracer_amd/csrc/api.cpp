@@ -101,8 +101,17 @@ struct mi355rt_scene {
    uint32_t *d_counters = nullptr;   // CNT_WORDS
    bool stats_valid = false;
    mi355rt_stats stats_accum {};
-   unsigned long long diag[16] = { 0 };
+   unsigned long long diag[N_STATS] = { 0 };
    FrameScratch scratch;
+   // MI355RT_COLLECT_TIMES: HIP events around each launch, resolved lazily (mi355rt_kernel_profile)
+   struct TimedLaunch {
+      hipEvent_t begin, end;
+      int kernel;
+   };
+   std::vector<TimedLaunch> pending_times;
+   std::vector<hipEvent_t> event_pool;
+   double kernel_ms[MI355RT_N_KERNELS] = { 0 };
+   uint64_t kernel_launches[MI355RT_N_KERNELS] = { 0 };
    // frame buffers of the host-buffer render entry point
    float *d_rgb = nullptr;
    int32_t *d_hit_id = nullptr;
@@ -134,8 +143,67 @@ void release_scene(mi355rt_scene *s)
    if (s->d_hit_id) (void) hipFree(s->d_hit_id);
    if (s->d_hit_w) (void) hipFree(s->d_hit_w);
    free_scratch(s->scratch);
+   for (const mi355rt_scene::TimedLaunch &t : s->pending_times) {
+      (void) hipEventDestroy(t.begin);
+      (void) hipEventDestroy(t.end);
+   }
+   for (hipEvent_t e : s->event_pool) (void) hipEventDestroy(e);
    delete s;
 }
+
+// waits for the pending timed launches and folds their durations into kernel_ms / kernel_launches
+int resolve_times(mi355rt_scene *s)
+{
+   for (const mi355rt_scene::TimedLaunch &t : s->pending_times) {
+      float ms = 0.0f;
+      hipError_t e = hipEventSynchronize(t.end);
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.begin, t.end);
+      s->event_pool.push_back(t.begin);
+      s->event_pool.push_back(t.end);
+      if (e != hipSuccess) {
+         s->pending_times.clear();
+         return hip_fail(e, "hipEventElapsedTime");
+      }
+      s->kernel_ms[t.kernel] += (double) ms;
+      s->kernel_launches[t.kernel] += 1;
+   }
+   s->pending_times.clear();
+   return MI355RT_OK;
+}
+
+// brackets one launch with events when the frame collects times
+class LaunchTimer {
+ public:
+   LaunchTimer(mi355rt_scene *s, bool on, hipStream_t stream) : s_(s), on_(on), stream_(stream) {}
+   template <typename F> hipError_t run(int kernel, F &&launch)
+   {
+      if (!on_) return launch();
+      hipEvent_t ev[2];
+      for (hipEvent_t &e : ev) {
+         if (!s_->event_pool.empty()) {
+            e = s_->event_pool.back();
+            s_->event_pool.pop_back();
+         } else if (hipError_t rc = hipEventCreate(&e); rc != hipSuccess) {
+            return rc;
+         }
+      }
+      hipError_t rc = hipEventRecord(ev[0], stream_);
+      if (rc == hipSuccess) rc = launch();
+      if (rc == hipSuccess) rc = hipEventRecord(ev[1], stream_);
+      if (rc != hipSuccess) {
+         s_->event_pool.push_back(ev[0]);
+         s_->event_pool.push_back(ev[1]);
+         return rc;
+      }
+      s_->pending_times.push_back({ ev[0], ev[1], kernel });
+      return hipSuccess;
+   }
+
+ private:
+   mi355rt_scene *s_;
+   bool on_;
+   hipStream_t stream_;
+};
 
 int upload(const void *src, size_t bytes, void **dst, mi355rt_scene *s)
 {
@@ -278,14 +346,17 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.micro_per_tile = (tile / 8) * (tile / 8);
    n_micro = owned * p.micro_per_tile;
    if (n_micro > 0x3fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups");
-   p.stats = st->collect_stats != 0;
+   p.stats = (st->collect_stats & MI355RT_COLLECT_COUNTS) != 0;
    return MI355RT_OK;
 }
 
 // one frame = passes of at most PASS_SLOTS sample slots, each a run of the kernel pipeline
-int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t stream)
+int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_times, hipStream_t stream)
 {
    if (n_micro == 0) return MI355RT_OK;
+   if (s->pending_times.size() > 4096)
+      if (int rc = resolve_times(s)) return rc;
+   LaunchTimer timer(s, collect_times, stream);
    const size_t slots_per_micro = (size_t) 64 * (size_t) p.multi_samples;
    const long long micro_per_pass = (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
    const long long first_pass = std::min(n_micro, micro_per_pass);
@@ -314,11 +385,14 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t str
       p.band_cap = (uint32_t) ((((unsigned long long) (m1 - m0) + N_BANDS - 1) / N_BANDS) * slots_per_micro);
       const unsigned long long slots = (unsigned long long) p.band_cap * N_BANDS;   // queue capacity of the pass
       HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
-      HIP_TRY(launch_generate(p, stream));
+      HIP_TRY(timer.run(MI355RT_K_GENERATE, [&] { return launch_generate(p, stream); }));
       int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
       auto next_cursor = [&]() -> int { return CNT_CURSOR0 + 8 * (cursor_set++); };
-      HIP_TRY(launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, next_cursor(), p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, stream));
-      HIP_TRY(launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream));
+      const int cw0 = next_cursor();
+      HIP_TRY(timer.run(MI355RT_K_WALK_PRIMARY, [&] {
+         return launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cw0, p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, stream);
+      }));
+      HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream); }));
       if (s->has_mirror) {
          // mirror bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
          int cur = 0;
@@ -334,22 +408,24 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, hipStream_t str
             const int cw = next_cursor();
             HIP_TRY(hipMemsetAsync(p.counters + cw, 0, 8 * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(p.counters + nxt_cnt, 0, N_BANDS * sizeof(uint32_t), stream));
-            HIP_TRY(launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, p.band_cap, n_sec, s->n_cus, p.stats ? 1 : 0, stream));
-            HIP_TRY(launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream));
+            HIP_TRY(timer.run(MI355RT_K_WALK_SECONDARY, [&] {
+               return launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, p.band_cap, n_sec, s->n_cus, p.stats ? 1 : 0, stream);
+            }));
+            HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream); }));
             cur ^= 1;
          }
       }
       if (p.lighting_model == MI355RT_LIGHTING_PHONG) {
          const int cw = CNT_CURSOR0 + 8 * (CNT_CURSOR_SETS - 1);
-         HIP_TRY(launch_shadow(p, cw, slots, s->n_cus, stream));
-         HIP_TRY(launch_phong(p, slots, s->n_cus, stream));
+         HIP_TRY(timer.run(MI355RT_K_WALK_SHADOW, [&] { return launch_shadow(p, cw, slots, s->n_cus, stream); }));
+         HIP_TRY(timer.run(MI355RT_K_PHONG, [&] { return launch_phong(p, slots, s->n_cus, stream); }));
       }
-      HIP_TRY(launch_resolve(p, stream));
+      HIP_TRY(timer.run(MI355RT_K_RESOLVE, [&] { return launch_resolve(p, stream); }));
       if (p.stats) {
-         unsigned long long h[16];
+         unsigned long long h[N_STATS];
          HIP_TRY(hipMemcpyAsync(h, p.counters + CNT_STATS, sizeof(h), hipMemcpyDeviceToHost, stream));
          HIP_TRY(hipStreamSynchronize(stream));
-         for (int q = 0; q < 16; q++) s->diag[q] = (m0 == 0 ? 0ull : s->diag[q]) + h[q];
+         for (int q = 0; q < N_STATS; q++) s->diag[q] = (m0 == 0 ? 0ull : s->diag[q]) + h[q];
          s->stats_accum.primary_rays += h[0];
          s->stats_accum.shadow_rays += h[1];
          s->stats_accum.secondary_rays += h[2];
@@ -657,7 +733,7 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
    p.hit_id = frame->hit_id;
    p.hit_obj = frame->hit_obj;
    p.hit_w = frame->hit_w;
-   return run_frame(scene, p, n_micro, (hipStream_t) hip_stream);
+   return run_frame(scene, p, n_micro, (settings->collect_stats & MI355RT_COLLECT_TIMES) != 0, (hipStream_t) hip_stream);
 }
 
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
@@ -703,6 +779,34 @@ int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
    if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
    if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
    *out = scene->stats_accum;   // run_frame reads the counters back at the end of each pass
+   return MI355RT_OK;
+}
+
+int mi355rt_kernel_profile(mi355rt_scene *scene, mi355rt_kernel_times *out, int reset)
+{
+   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   if (int rc = resolve_times(scene)) return rc;
+   std::memset(out, 0, sizeof(*out));
+   for (int k = 0; k < MI355RT_N_KERNELS; k++) {
+      out->ms[k] = scene->kernel_ms[k];
+      out->launches[k] = scene->kernel_launches[k];
+   }
+   if (scene->stats_valid) {
+      const int kinds[3] = { MI355RT_K_WALK_PRIMARY, MI355RT_K_WALK_SECONDARY, MI355RT_K_WALK_SHADOW };
+      for (int q = 0; q < 3; q++) {   // trace_kernels.hip: ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22
+         out->rays[kinds[q]] = scene->diag[16 + q];
+         out->box_tests[kinds[q]] = scene->diag[19 + q];
+         out->tri_tests[kinds[q]] = scene->diag[22 + q];
+      }
+   }
+   if (reset) {
+      for (int k = 0; k < MI355RT_N_KERNELS; k++) {
+         scene->kernel_ms[k] = 0.0;
+         scene->kernel_launches[k] = 0;
+      }
+   }
    return MI355RT_OK;
 }
 

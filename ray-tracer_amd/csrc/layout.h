@@ -92,10 +92,11 @@ enum {
    CNT_SHADOW = 8,    // shadow list sizes          [N_BANDS]
    CNT_SEC_A = 16,    // secondary queues (ping-pong) [N_BANDS] each
    CNT_SEC_B = 24,
-   CNT_STATS = 32,    // 16 x 64-bit stats counters (u32 pairs): 6 public + walker diagnostics
-   CNT_CURSOR0 = 64,  // work cursors of the persistent launches: N_BANDS per launch
+   CNT_STATS = 32,    // N_STATS x 64-bit stats counters (u32 pairs): 6 public, walker diagnostics, per-kernel counts
+   N_STATS = 32,
+   CNT_CURSOR0 = 96,  // work cursors of the persistent launches: N_BANDS per launch
    CNT_CURSOR_SETS = 8,
-   CNT_WORDS = 64 + 8 * 8
+   CNT_WORDS = 96 + 8 * 8
 };
 
 struct FrameArgs {

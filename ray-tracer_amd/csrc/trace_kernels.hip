@@ -180,7 +180,9 @@ __device__ __forceinline__ void add_stat(uint32_t *counters, int which, unsigned
 }
 enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, ST_HITS = 5,
        // walker diagnostics (collect_stats builds only): lane-trips and wave-trips of each phase
-       ST_NODE_LANE = 6, ST_NODE_WAVE = 7, ST_LEAF_LANE = 8, ST_LEAF_WAVE = 9, ST_OUTER_WAVE = 10, ST_REFILL = 11 };
+       ST_NODE_LANE = 6, ST_NODE_WAVE = 7, ST_LEAF_LANE = 8, ST_LEAF_WAVE = 9, ST_OUTER_WAVE = 10, ST_REFILL = 11,
+       // per walker launch kind (0 primary, 1 secondary, 2 shadow): rays, box tests, triangle tests
+       ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22 };
 
 // true on exactly one of the currently active lanes
 __device__ __forceinline__ bool first_active_lane()
@@ -911,6 +913,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
       add_stat(a.counters, ST_TRI, n_tri);
       if (MODE != MODE_CLOSEST) add_stat(a.counters, ST_SHADOW, n_ray);
       add_stat(a.counters, ST_HITS, a.stats == 2 ? n_hit : 0u);
+      const int kind = MODE != MODE_CLOSEST ? 2 : (a.stats == 2 ? 0 : 1);
+      add_stat(a.counters, ST_KIND_RAYS + kind, n_ray);
+      add_stat(a.counters, ST_KIND_BOX + kind, n_box);
+      add_stat(a.counters, ST_KIND_TRI + kind, n_tri);
       add_stat(a.counters, ST_NODE_LANE, d_node_lane);
       add_stat(a.counters, ST_NODE_WAVE, d_node_wave);
       add_stat(a.counters, ST_LEAF_LANE, n_tri);
@@ -1206,7 +1212,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.stats = stats;
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
-   a.both_min = tunable("MI355RT_BOTH_MIN", 20);
+   a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats != 0, stream);
 }
 
@@ -1253,7 +1259,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.stats = p.stats;
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
-   a.both_min = tunable("MI355RT_BOTH_MIN", 20);
+   a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    const unsigned grid = persistent_grid(n_cus, max_items);
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, p.stats != 0, stream);
    return launch_walk<MODE_SHADOW>(a, grid, p.stats != 0, stream);

@@ -303,7 +303,7 @@ class Camera:
         self.hit_w = None
         self.lightingModel.setCamera(self)
 
-    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False):
+    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False, collect_times=False):
         st = _abi.Settings()
         st.epsilon = RTStatics.EPSILON
         st.near_plane = RTStatics.NEAR_PLANE
@@ -320,7 +320,7 @@ class Camera:
         st.tile_size = tile_size
         st.tile_rank = tile_rank
         st.tile_world = tile_world
-        st.collect_stats = 1 if collect_stats else 0
+        st.collect_stats = (_abi.COLLECT_COUNTS if collect_stats else 0) | (_abi.COLLECT_TIMES if collect_times else 0)
         return st
 
     def addActionListener(self, listener):
@@ -351,6 +351,12 @@ class Camera:
         s = _abi.Stats()
         _abi.check(self._lib.mi355rt_frame_stats(self.scene._handle, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _abi.Stats._fields_}
+
+    def kernel_profile(self, reset=False):
+        """mi355rt_kernel_profile: {kernel name: {ms, launches, rays, box_tests, tri_tests}}."""
+        kp = _abi.KernelProfile()
+        _abi.check(self._lib.mi355rt_kernel_profile(self.scene._handle, C.byref(kp), 1 if reset else 0))
+        return {name: {f: getattr(kp, f)[k] for f, _ in _abi.KernelProfile._fields_} for k, name in enumerate(_abi.KERNEL_NAMES)}
 
     def debug_counters(self):
         out = (C.c_uint64 * 16)()

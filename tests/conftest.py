@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# One process holds one HIP runtime: torch bundles its own libamdhip64.so.7 and libmi355rt.so asks for the
+# same soname, so whichever is loaded first serves both.  torch only finds the GPU through its own copy,
+# so tests that use torch tensors beside the library need torch imported first (bench.py does the same).
+try:
+    import torch  # noqa: F401
+except ImportError:   # the library itself does not need torch
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

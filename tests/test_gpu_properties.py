@@ -1,0 +1,198 @@
+"""Full-size and size-independent checks of the HIP path (through the C ABI): the BASELINE configuration
+against the oracle, tile sharding, multi-pass frames, determinism, counter identities, error behaviour."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rt, faces, name="dragon", color=None, extra=()):
+    cfg = rt.meshgen.STANFORD[name]
+    v, i = rt.meshgen.stanford_standin(name, faces)
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+    meshes = [rt.TriangleMesh((v, i), color or rt.ColorInformation((0.9, 0.9, 0.9)), True)] + list(extra)
+    scene = rt.Scene(meshes, light, cfg["orientation"], rt.PhongLightingModel(light, meshes), cfg["fov"])
+    return scene, (v, i), cfg, light
+
+
+def _device_frame(rt, cam, **kw):
+    import torch
+    W, H = cam.screenWidth, cam.screenHeight
+    dev = torch.device("cuda", 0)
+    rgb = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+    hid = torch.full((H, W), -5, dtype=torch.int32, device=dev)
+    hw = torch.full((H, W), -1.0, dtype=torch.float32, device=dev)
+    frame = rt._abi.Frame(rgb.data_ptr(), None, hid.data_ptr(), None, hw.data_ptr())
+    return frame, rgb, hid, hw
+
+
+def test_dragon_config_full_size_vs_oracle(rt, orc):
+    """BASELINE configs[1]: Dragon-class mesh (871,414 faces), 1920x1080, 4 spp, Phong, primary + shadow --
+    the whole frame against the oracle: ids and w bit-exact, radiance within 1e-3 relative."""
+    from helpers import compare_frames
+    scene, (v, i), cfg, light = _scene(rt, None)
+    cam = rt.Camera(scene, 4, 1, rt.RTStatics.NEAR_PLANE, 1920, 1080, rng_seed=2024)
+    cam.createImage()
+    osc = orc.OracleScene([(v, i, None, orc.material(diffuse=(0.9, 0.9, 0.9)))])
+    ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, 1920, 1080)
+    ost = orc.settings(epsilon=osc.epsilon(), ms=4, lighting=1, seed=2024, light_origin=light.origin,
+                       light_emission=light.emission, light_ambient=light.ambient)
+    o = osc.render(ocam, ost, n_threads=16)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o)
+    assert ids_equal, "%d pixels differ in hit id" % n_diff
+    assert w_equal
+    assert max_rel <= 1e-3, max_rel
+    assert 0.2 < float((o["hit_id"] >= 0).mean()) < 0.9
+    osc.close()
+    scene.close()
+
+
+def test_tile_shards_merge_to_the_whole_frame(rt):
+    """Three ranks' tiles written into one frame equal the single-rank frame bit for bit; a rank writes
+    nothing outside its tiles."""
+    import torch
+    from ray_tracer_amd import tiles
+    scene, _, _, _ = _scene(rt, 30000)
+    W, H = 200, 120
+    cam = rt.Camera(scene, 2, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=7)
+    f1, rgb1, id1, w1 = _device_frame(rt, cam)
+    cam.render_device(f1)
+    torch.cuda.synchronize()
+    assert bool((id1 >= -1).all())
+    f3, rgb3, id3, w3 = _device_frame(rt, cam)
+    for world, tile in ((3, 16), (2, 32)):
+        id3.fill_(-5)
+        for r in range(world):
+            before = id3.clone()
+            cam.render_device(f3, tile_rank=r, tile_world=world, tile_size=tile)
+            torch.cuda.synchronize()
+            pix = tiles.tile_pixels(W, H, tiles.owned_tiles(W, H, r, world, tile), tile)
+            own = torch.zeros(W * H, dtype=torch.bool)
+            own[pix[pix >= 0]] = True
+            own = own.reshape(H, W).to(id3.device)
+            assert torch.equal(id3[~own], before[~own])          # other ranks' tiles untouched
+        assert torch.equal(id3, id1) and torch.equal(w3, w1) and torch.equal(rgb3, rgb1)
+    scene.close()
+
+
+def test_multi_pass_frame(rt, orc):
+    """A frame of more than 2^24 sample slots runs as several passes of the pipeline (api.cpp PASS_SLOTS)."""
+    from helpers import compare_frames
+    scene, (v, i), cfg, light = _scene(rt, 5000, name="bunny")
+    W, H, ms = 1920, 1088, 9       # 18.8 M samples -> 2 passes
+    cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=3)
+    cam.createImage()
+    osc = orc.OracleScene([(v, i, None, orc.material(diffuse=(0.9, 0.9, 0.9)))])
+    ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, W, H)
+    ost = orc.settings(epsilon=osc.epsilon(), ms=ms, lighting=1, seed=3, light_origin=light.origin,
+                       light_emission=light.emission, light_ambient=light.ambient)
+    o = osc.render(ocam, ost, n_threads=16)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o)
+    assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
+    osc.close()
+    scene.close()
+
+
+def test_determinism_and_counter_identities(rt):
+    """Two renders are bit-identical (whatever wave walked which ray or stole which subtree), and the
+    counters obey: primary = W*H*spp, shadow = hits (one shadow ray per hit sample, RTStatics.java:617),
+    per-kernel counts add up."""
+    import torch
+    scene, _, _, _ = _scene(rt, 100000)
+    W, H, ms = 320, 200, 4
+    cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=11)
+    fa, rgba, ida, wa = _device_frame(rt, cam)
+    fb, rgbb, idb, wb = _device_frame(rt, cam)
+    cam.render_device(fa, collect_stats=True, collect_times=True)
+    torch.cuda.synchronize()
+    st = cam.frame_stats()
+    cam.render_device(fb)
+    torch.cuda.synchronize()
+    assert torch.equal(ida, idb) and torch.equal(wa, wb) and torch.equal(rgba, rgbb)
+    assert st["primary_rays"] == W * H * ms
+    assert st["shadow_rays"] == st["hits"] > 0
+    assert st["secondary_rays"] == 0
+    kp = cam.kernel_profile(reset=True)
+    # the primary queue holds only the samples whose ray meets some object's box (the rest are misses at generation)
+    assert st["hits"] <= kp["walk_primary"]["rays"] <= st["primary_rays"]
+    assert kp["walk_shadow"]["rays"] == st["shadow_rays"]
+    assert kp["walk_primary"]["tri_tests"] + kp["walk_shadow"]["tri_tests"] == st["tri_tests"]
+    for name in ("generate", "walk_primary", "shade", "walk_shadow", "phong", "resolve"):
+        assert kp[name]["launches"] == 1 and kp[name]["ms"] > 0.0
+    assert kp["walk_secondary"]["launches"] == 0
+    assert cam.kernel_profile()["walk_primary"]["launches"] == 0      # reset
+    scene.close()
+
+
+def test_mirror_bounces_between_two_mirrors(rt, orc):
+    """Two facing mirrors: paths bounce until max_mirror_bounces cuts them (the reference would recurse
+    without bound, bounds/KDTree.java:77-80; the oracle carries the same guard)."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(3000, span=0.2, seed=31)
+    v2, i2 = rt.meshgen.blob(2000, span=0.15, seed=32, center=(0.2, 0.0, 0.0))
+    fv, fi = rt.meshgen.quad(-0.12, 0.3, center=(0.1, 0.0))
+    pair = Pair([(v, i, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))), (v2, i2, None, rt.ReflectionMaterial((1.0, 0.8, 0.8))),
+                 (fv, fi, None, rt.ColorInformation((0.3, 0.8, 0.2)))], orientation=(0, -15, 0), fov=25.0)
+    from helpers import compare_frames
+    cam, ocam, ost = pair.cameras(160, 100, ms=2, seed=17)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=8, want_stats=True)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o)
+    assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
+    assert o["stats"]["secondary_rays"] > 1000
+    pair.close()
+
+
+def test_error_behaviour(rt):
+    """Bad arguments come back as error codes with a message, never as a fault."""
+    lib = rt._abi.load()
+    scene, _, _, _ = _scene(rt, 2000, name="bunny")
+    cam = rt.Camera(scene, 1, 1, rt.RTStatics.NEAR_PLANE, 32, 32)
+    st = cam.settings()
+    st.multi_samples = 0
+    rc = lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None)
+    assert rc == rt._abi.E_ARG and b"multi_samples" in lib.mi355rt_last_error()
+    st = cam.settings(tile_rank=2, tile_world=2)
+    assert lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None) == rt._abi.E_ARG
+    st = cam.settings(tile_size=12)
+    assert lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None) == rt._abi.E_ARG
+    # a BRDF material whose row is outside the loaded tables (8 rows)
+    from helpers import synthetic_brdf_tables
+    v, i = rt.meshgen.blob(500, span=0.2)
+    rt.BRDFMaterial.setTables(*synthetic_brdf_tables())
+    light = rt.Light((0, 100, 100), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+    m = rt.TriangleMesh((v, i), rt.BRDFMaterial(50, (0.2, 0.8, 0.3)), True)
+    s2 = rt.Scene([m], light, (0, 0, 0), rt.PhongLightingModel(light, [m]), 15.0)
+    c2 = rt.Camera(s2, 1, 1, rt.RTStatics.NEAR_PLANE, 16, 16)
+    with pytest.raises(rt._abi.Mi355rtError) as e:
+        c2.createImage()
+    assert e.value.code == rt._abi.E_ARG
+    # an index out of range is refused at scene build
+    bad = i.copy()
+    bad[7, 1] = v.shape[0]
+    with pytest.raises(rt._abi.Mi355rtError):
+        rt.Scene([rt.TriangleMesh((v, bad), rt.ColorInformation((1, 1, 1)), True)], light, (0, 0, 0), rt.LightingModel(), 15.0)
+    s2.close()
+    scene.close()
+
+
+def test_empty_and_degenerate_meshes(rt, orc):
+    """An empty mesh beside a real one, and a mesh with zero-area and NaN-normal faces."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(1500, span=0.2, seed=41)
+    i = i.copy()
+    i[10] = (i[10, 0], i[10, 0], i[10, 1])         # zero-area face: NaN normals at its vertices (TriangleMesh.java:96-126)
+    ev = np.zeros((3, 3), dtype=np.float32)
+    ei = np.zeros((0, 3), dtype=np.int32)
+    pair = Pair([(v, i, None, rt.ColorInformation((1, 1, 1))), (ev, ei, None, rt.ColorInformation((1, 0, 0)))], fov=15.0)
+    cam, ocam, ost = pair.cameras(96, 96)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=4)
+    assert np.array_equal(cam.hit_id.T, o["hit_id"])
+    assert np.array_equal(cam.hit_w.T.view(np.uint32), o["hit_w"].view(np.uint32))
+    both_nan = np.isnan(cam._rgb_rows) & np.isnan(o["rgb"])
+    close = np.abs(cam._rgb_rows - o["rgb"]) <= 1e-3 * np.maximum(np.abs(o["rgb"]), 1e-3)
+    assert (both_nan | close).all()
+    pair.close()
