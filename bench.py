@@ -140,6 +140,9 @@ def main():
     kernels = {name: {"ms_per_launch": round(v["ms"] / v["launches"], 4), "launches_per_frame": v["launches"] / args.steps,
                       "ms_per_frame": round(v["ms"] / args.steps, 4)}
                for name, v in kprof.items() if v["launches"]}
+    for name, v in kernels.items():
+        if kcounts[name]["rays"]:
+            v.update(rays=kcounts[name]["rays"], box_tests=kcounts[name]["box_tests"], tri_tests=kcounts[name]["tri_tests"])
     dom = max(kernels, key=lambda n: kernels[n]["ms_per_frame"])
     lp, ls, lsec, lb, lt, lh = [float(x) for x in local_counts.tolist()]
     own_pixels = float(sharder.my_pix.ge(0).sum().item())
