@@ -94,6 +94,7 @@ typedef struct {
 
 #define MI355RT_COLLECT_COUNTS 1
 #define MI355RT_COLLECT_TIMES 2
+#define MI355RT_COLLECT_DIAG 4   /* counts plus the walker's lane-utilisation diagnostics (mi355rt_debug_counters); slower */
 
 /* the kernels of one frame (the wavefront pipeline of DESIGN.md), as indices into mi355rt_kernel_times */
 enum {
@@ -206,10 +207,11 @@ void mi355rt_free(void *p);
 int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_div, float *out_sqrt, float *out_rnorm,
                         float *out_pow);
 
-/* Diagnostic: the 16 raw 64-bit counters of the most recent collect_stats render: [0..5] = mi355rt_stats,
- * [6..11] = lane-trips / wave-trips of the walker's node and leaf loops, outer trips, refills.
- * No counterpart in the reference. */
-int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[16]);
+/* Diagnostic: the 64 raw 64-bit counters of the most recent collect_stats render: [0..5] = mi355rt_stats,
+ * [6..15] = lane-trips / wave-trips of the walker's node and leaf loops, outer trips, refills, steals, wave
+ * lifetimes; [16..24] per-walker rays / box tests / triangle tests; [25..42] per-walker timeline, [43..58] rays by trips taken
+ * (trace_kernels.hip ST_*).  No counterpart in the reference. */
+int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[64]);
 
 const char *mi355rt_last_error(void);
 int mi355rt_abi_version(void);

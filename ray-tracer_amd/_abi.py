@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355rt.so")
+# MI355RT_LIB: tuning builds only (tools/variants.sh); the product is the in-tree libmi355rt.so
+LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")
 
 MAT_COLOR, MAT_BRDF, MAT_REFLECTION = 0, 1, 2
 LIGHTING_PLAIN, LIGHTING_PHONG = 0, 1
@@ -56,7 +57,7 @@ class Stats(C.Structure):
                 ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("hits", C.c_uint64)]
 
 
-COLLECT_COUNTS, COLLECT_TIMES = 1, 2
+COLLECT_COUNTS, COLLECT_TIMES, COLLECT_DIAG = 1, 2, 4
 K_GENERATE, K_WALK_PRIMARY, K_SHADE, K_WALK_SECONDARY, K_WALK_SHADOW, K_PHONG, K_RESOLVE, N_KERNELS = 0, 1, 2, 3, 4, 5, 6, 8
 KERNEL_NAMES = ("generate", "walk_primary", "shade", "walk_secondary", "walk_shadow", "phong", "resolve")
 

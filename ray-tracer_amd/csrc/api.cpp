@@ -346,7 +346,8 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.micro_per_tile = (tile / 8) * (tile / 8);
    n_micro = owned * p.micro_per_tile;
    if (n_micro > 0x3fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups");
-   p.stats = (st->collect_stats & MI355RT_COLLECT_COUNTS) != 0;
+   p.stats = (st->collect_stats & (MI355RT_COLLECT_COUNTS | MI355RT_COLLECT_DIAG)) != 0;
+   p.diag = (st->collect_stats & MI355RT_COLLECT_DIAG) != 0;
    return MI355RT_OK;
 }
 
@@ -390,7 +391,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       auto next_cursor = [&]() -> int { return CNT_CURSOR0 + 8 * (cursor_set++); };
       const int cw0 = next_cursor();
       HIP_TRY(timer.run(MI355RT_K_WALK_PRIMARY, [&] {
-         return launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cw0, p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, stream);
+         return launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cw0, p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, p.diag, stream);
       }));
       HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream); }));
       if (s->has_mirror) {
@@ -409,7 +410,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
             HIP_TRY(hipMemsetAsync(p.counters + cw, 0, 8 * sizeof(uint32_t), stream));
             HIP_TRY(hipMemsetAsync(p.counters + nxt_cnt, 0, N_BANDS * sizeof(uint32_t), stream));
             HIP_TRY(timer.run(MI355RT_K_WALK_SECONDARY, [&] {
-               return launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, p.band_cap, n_sec, s->n_cus, p.stats ? 1 : 0, stream);
+               return launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, p.band_cap, n_sec, s->n_cus, p.stats ? 1 : 0, p.diag, stream);
             }));
             HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream); }));
             cur ^= 1;
@@ -573,10 +574,10 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
             s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
          }
       }
-      // one padding slot: a prefetching walk may read one slot past the last leaf
-      all_tris.resize(12 * (slot_total + 1), 0.0f);
+      // padding slots: a walker reads a few slots past the end of a leaf
+      all_tris.resize(12 * (slot_total + LEAF_PAD_SLOTS), 0.0f);
       const int32_t one = 1;
-      std::memcpy(&all_tris[12 * slot_total + 7], &one, sizeof(float));
+      for (int q = 0; q < LEAF_PAD_SLOTS; q++) std::memcpy(&all_tris[12 * (slot_total + q) + 7], &one, sizeof(float));
    } catch (const std::bad_alloc &) {
       release_scene(s);
       return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
@@ -810,11 +811,12 @@ int mi355rt_kernel_profile(mi355rt_scene *scene, mi355rt_kernel_times *out, int 
    return MI355RT_OK;
 }
 
-int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[16])
+int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[64])
 {
    if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
    if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
-   for (int q = 0; q < 16; q++) out[q] = scene->diag[q];
+   static_assert(N_STATS == 64, "mi355rt_debug_counters hands out N_STATS values");
+   for (int q = 0; q < N_STATS; q++) out[q] = scene->diag[q];
    return MI355RT_OK;
 }
 
@@ -867,7 +869,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    a.out_normal = (float *) buf.p[9];
    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, CNT_WORDS * sizeof(uint32_t), nullptr));
    HIP_TRY(launch_batch_pack(a, nullptr));
-   HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, a.band_cap, n, scene->n_cus, 0, nullptr));
+   HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, a.band_cap, n, scene->n_cus, 0, 0, nullptr));
    HIP_TRY(launch_batch_unpack(a, nullptr));
    HIP_TRY(hipStreamSynchronize(nullptr));
    if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[5], sizes[5], hipMemcpyDeviceToHost));

@@ -17,7 +17,7 @@
 //   tris  : one 48-byte slot per (leaf, face) pair, leaves in left-to-right DFS order, faces in
 //           the reference's stored order (straddlers are duplicated exactly as KDNode.java:58-69
 //           duplicates them).  slot = 3 x float4 { v0.xyz, faceId }, { v1.xyz, faces left in this leaf },
-//           { v2.xyz, 0 }; one zero padding slot follows the last leaf.
+//           { v2.xyz, 0 }; LEAF_PAD_SLOTS zero slots follow the last leaf.
 //           Because leaves are laid out in DFS order, the first-slot index of a leaf is also the
 //           leaf's rank in the reference's fold order (the tie rule of KDNode.java:105,114).
 //   fnrm  : 48 bytes per FACE (not per slot): the three vertex normals, fetched once per final hit.
@@ -42,6 +42,7 @@ constexpr int MAX_TREE_DEPTH = 22;   // build_opts.max_depth limit (the referenc
 constexpr int STACK_SLOTS = 24;      // >= MAX_TREE_DEPTH + 2
 constexpr int MAX_OBJECTS = 64;
 constexpr int BLOCK_THREADS = 256;
+constexpr int LEAF_PAD_SLOTS = 8;    // zero slots after the last leaf: a walker may read a few slots past a leaf's end
 
 struct NodeRec {   // 64 B
    float lmin[3], lmax[3];
@@ -93,10 +94,10 @@ enum {
    CNT_SEC_A = 16,    // secondary queues (ping-pong) [N_BANDS] each
    CNT_SEC_B = 24,
    CNT_STATS = 32,    // N_STATS x 64-bit stats counters (u32 pairs): 6 public, walker diagnostics, per-kernel counts
-   N_STATS = 32,
-   CNT_CURSOR0 = 96,  // work cursors of the persistent launches: N_BANDS per launch
+   N_STATS = 64,
+   CNT_CURSOR0 = 160,  // work cursors of the persistent launches: N_BANDS per launch
    CNT_CURSOR_SETS = 8,
-   CNT_WORDS = 96 + 8 * 8
+   CNT_WORDS = 160 + 8 * 8
 };
 
 struct FrameArgs {
@@ -134,7 +135,8 @@ struct FrameArgs {
    uint32_t *argb8;
    int32_t *hit_id, *hit_obj;
    float *hit_w;
-   int32_t stats;
+   int32_t stats;   // count rays / tests (walker template level 1)
+   int32_t diag;    // walker diagnostics on top (level 2)
 };
 
 struct TraceBatchArgs {   // mi355rt_trace_rays

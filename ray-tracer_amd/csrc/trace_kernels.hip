@@ -182,7 +182,12 @@ enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, 
        // walker diagnostics (collect_stats builds only): lane-trips and wave-trips of each phase
        ST_NODE_LANE = 6, ST_NODE_WAVE = 7, ST_LEAF_LANE = 8, ST_LEAF_WAVE = 9, ST_OUTER_WAVE = 10, ST_REFILL = 11,
        // per walker launch kind (0 primary, 1 secondary, 2 shadow): rays, box tests, triangle tests
-       ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22 };
+       ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22,
+       // per kind, 6 slots each: ~min t_begin, ~min t_queue_dry, max t_queue_dry, max t_end (100 MHz ticks), most trips of one ray, waves that got a ray
+       ST_KIND_TIMELINE = 25,
+       // rays of the LAST walker launch by trips taken: < 16, 32, 64, 128, 256, 512, 1024, more (8 slots per kind: primary 43.., shadow 51..)
+       ST_TRIP_HIST = 43,
+       ST_TAIL_TRIPS = 59 };   // {max, sum} of wave trips after the queue ran dry: primary 59,60; shadow 61,62
 
 // true on exactly one of the currently active lanes
 __device__ __forceinline__ bool first_active_lane()
@@ -528,19 +533,23 @@ struct WalkArgs {
 
 // lane roles
 enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
-constexpr bool FETCH_DMA = false;   // record fetch through LDS (global_load_lds) instead of per-lane loads
+#ifndef WALK_WAVES_PER_SIMD
+#define WALK_WAVES_PER_SIMD 6
+#endif
+#ifndef WALK_LEAF_BATCH
+#define WALK_LEAF_BATCH 2
+#endif
+constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip (<= LEAF_PAD_SLOTS + 1)
 
-template <bool STATS, int MODE>
-__global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
+template <int STATS, int MODE>   // STATS: 0 none, 1 counts + timeline (light), 2 + walker diagnostics (heavy, changes occupancy)
+__global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(WALK_WAVES_PER_SIMD, WALK_WAVES_PER_SIMD))) void walk_kernel(const WalkArgs a)
 {
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
    __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
-   __shared__ float4 s_stage[FETCH_DMA ? 4 * BLOCK_THREADS : 1];      // 64 B per lane: this trip's record
    const int lane = threadIdx.x & 63;
    const int wave_base = threadIdx.x & ~63;
    int *__restrict__ stack = s_stack + threadIdx.x;
    volatile int *list = s_list + wave_base;
-   float4 *stage = s_stage + (FETCH_DMA ? 4 * wave_base : 0);
    const unsigned long long lanes_below = (1ull << lane) - 1ull;
    uint32_t *cursors = a.counters + a.cursor_index;
    const float4 *__restrict__ nodes = (const float4 *) a.sc.nodes;
@@ -568,12 +577,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
    bool occluded = false;
    int s = 0, leaf0 = 0;   // current slot / first slot of the current leaf (valid while cur < 0)
    unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0;
-   unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
+   unsigned d_ray_trips = 0, d_ray_trips_max = 0;
+   unsigned d_hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+   unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_lane = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
    const unsigned long long t_begin = STATS ? wall_clock64() : 0ull;   // 100 MHz
    unsigned long long t_exhausted = 0ull;
+   unsigned d_tail_trips = 0;   // wave trips after the queue ran dry
 
    for (;;) {
-      if (STATS && lane == 0) d_outer++;
+      if (STATS > 1 && lane == 0) d_outer++;
+      if (STATS && exhausted) d_tail_trips++;
       if (__ballot(cur == STACK_EMPTY) != 0ull) {
          // ---- (1) helpers that finished their subtree hand (w, slot, leaf) to the ray's owner, which
          // folds it in with the same order-independent rule the leaves use
@@ -671,7 +684,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
          const unsigned long long idle = __ballot(role == ROLE_IDLE);
          if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             const unsigned want_n = (unsigned) __popcll(idle);
-            if (STATS && lane == 0) d_refill++;
+            if (STATS > 1 && lane == 0) d_refill++;
             unsigned base = 0, limit = 0;
             bool got = false;
             while (attempt < N_BANDS) {
@@ -723,6 +736,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
                   best_w = 0.0f;
                   occluded = false;
                   if (STATS) n_ray++;
+                  if (STATS > 1) {
+                     d_ray_trips_max = max(d_ray_trips_max, d_ray_trips);
+                     if (n_ray > 1) {
+                        const int bin = d_ray_trips < 16 ? 0 : min(7, 28 - __clz(d_ray_trips));
+#pragma unroll
+                        for (int q = 0; q < 8; q++) d_hist[q] += (q == bin) ? 1u : 0u;
+                     }
+                     d_ray_trips = 0;
+                  }
                }
             }
          }
@@ -765,7 +787,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
                ob_slot = -1;
                ob_w = 0.0f;
                ob_key = 0;
-               if (STATS) d_steal++;
+               if (STATS > 1) d_steal++;
             }
             unsigned long long tm = __ballot(is_thief);
             while (tm != 0ull) {
@@ -787,57 +809,39 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
       // ---- one step per lane: an internal node (C) or one face of a leaf (D).  A trip that ran both
       // paths for a handful of lanes each would spend most of its issue slots on masked-off lanes, so
       // the minority state sits a trip out unless it is populous too (it becomes the majority soon).
+      if (STATS > 1 && role == ROLE_OWNER) d_ray_trips++;
       const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
       const bool in_leaf = cur < 0;
       const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
       const bool both = n_node >= a.both_min && n_leaf >= a.both_min;
       const bool is_node = in_node && (both || n_node >= n_leaf);
       const bool is_leaf = in_leaf && (both || n_leaf > n_node);
-      float4 na, nb, nc, A, B, C;
-      int4 nd;
-      if (FETCH_DMA) {
-         // Every lane needs ONE record this trip: a 64-byte node or a 48-byte leaf slot, at an address
-         // of its own.  Four neighbouring lanes fetch one owner's record as one contiguous 64 bytes,
-         // straight into LDS (global_load_lds, 16 B per lane): instruction j serves lanes 16j..16j+15,
-         // so the wave's 64 records take 4 instructions of 16 x 64-byte segments each.  Every lane then
-         // reads its own record back from LDS.  The 16-byte chunks of a record are stored rotated by
-         // (lane >> 2) & 3 so that the 128-bit LDS reads are bank-conflict free.  (A leaf slot's 4th
-         // chunk is the first 16 bytes of the next slot: read, never used.)
-         const int code = is_node ? cur : (is_leaf ? ~s : 0);   // >= 0: node index, < 0: ~slot
+      // One fetch per lane per trip, issued up front for every lane so that the latencies overlap: a node lane
+      // reads its 64-byte record, a leaf lane the next LEAF_BATCH slots of its leaf (contiguous, 48 bytes each;
+      // the array is padded so that reading past the last leaf is harmless).  Lanes sitting the trip out read
+      // slot 0.  Testing several faces of a leaf per trip divides the number of dependent round trips to memory,
+      // which is what a leaf costs (the arithmetic is the same).
+      constexpr int NQ = 3 * LEAF_BATCH > 4 ? 3 * LEAF_BATCH : 4;
+      float4 q[NQ];
+      {
+         const float4 *src = is_node ? nodes + 4 * (size_t) cur : tris + 3 * (size_t) (is_leaf ? s : 0);
 #pragma unroll
-         for (int j = 0; j < 4; j++) {
-            const int rec_lane = j * 16 + (lane >> 2);
-            const int ocode = __shfl(code, rec_lane, 64);
-            const int chunk = (lane & 3) ^ ((rec_lane >> 2) & 3);
-            const char *src = ocode >= 0 ? (const char *) nodes + (size_t) ocode * 64 : (const char *) tris + (size_t) (~ocode) * 48;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + chunk * 16),
-                                             (__attribute__((address_space(3))) void *) (stage + j * 64), 16, 0, 0);
+         for (int j = 0; j < 4; j++) q[j] = src[j];
+         if (NQ > 4) {
+#pragma unroll
+            for (int j = 4; j < NQ; j++) q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (is_leaf) {
+#pragma unroll
+               for (int j = 4; j < NQ; j++) q[j] = src[j];
+            }
          }
-         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-         const int rot = (lane >> 2) & 3;
-         const float4 *mine = stage + lane * 4;
-         const float4 q0 = mine[0 ^ rot], q1 = mine[1 ^ rot], q2 = mine[2 ^ rot], q3 = mine[3 ^ rot];
-         na = A = q0;
-         nb = B = q1;
-         nc = C = q2;
-         nd = make_int4(__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w));
-      } else {
-         // both fetches are issued up front, for every lane (lanes not in that state read record 0), so
-         // that their latencies overlap and the compiler has no branch to sink them under
-         const float4 *rec = nodes + 4 * (size_t) (is_node ? cur : 0);
-         const float4 *t = tris + 3 * (size_t) (is_leaf ? s : 0);
-         na = rec[0];
-         nb = rec[1];
-         nc = rec[2];
-         nd = *(const int4 *) (rec + 3);
-         A = t[0];
-         B = t[1];
-         C = t[2];
       }
+      const float4 na = q[0], nb = q[1], nc = q[2];
+      const int4 nd = make_int4(__float_as_int(q[3].x), __float_as_int(q[3].y), __float_as_int(q[3].z), __float_as_int(q[3].w));
 
       if (is_node) {
          // (C) both children of one internal node
-         if (STATS) {
+         if (STATS > 1) {
             d_node_lane++;
             if (first_active_lane()) d_node_wave++;
          }
@@ -875,27 +879,35 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
       }
 
       if (is_leaf) {
-         // (D) one face of a leaf (KDNode.java:110-118), folded into object k's best.  The slot's second
-         // float4 carries in .w how many faces of the leaf remain from that slot on.
-         if (STATS) {
-            n_tri++;
+         // (D) up to LEAF_BATCH faces of a leaf (KDNode.java:110-118), folded into object k's best in slot order.
+         // The slot's second float4 carries in .w how many faces of the leaf remain from that slot on.
+         if (STATS > 1) {
+            d_leaf_lane++;
             if (first_active_lane()) d_leaf_wave++;
          }
-         float u, v, dist;
-         V3 P;
-         bool stop = __float_as_int(B.w) <= 1;
-         if (tri_test(A, B, C, r, eps, u, v, P, dist) && (dist > sd) &&
-             (ob_slot < 0 || dist < ob_w || (dist == ob_w && leaf0 > ob_key))) {
-            ob_w = dist;
-            ob_slot = s;
-            ob_key = leaf0;
-            lim2 = fminf(lim2, prune_limit2(r, dist));
-            if (MODE == MODE_SHADOW_ANY) {
-               stop = true;
-               sp = bot;
+         const int n_left = __float_as_int(q[1].w);
+         bool stop = n_left <= LEAF_BATCH;
+#pragma unroll
+         for (int j = 0; j < LEAF_BATCH; j++) {
+            if (j < n_left) {
+               if (STATS) n_tri++;
+               float u, v, dist;
+               V3 P;
+               if (tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist) && (dist > sd) &&
+                   (ob_slot < 0 || dist < ob_w || (dist == ob_w && leaf0 > ob_key))) {
+                  ob_w = dist;
+                  ob_slot = s + j;
+                  ob_key = leaf0;
+                  lim2 = fminf(lim2, prune_limit2(r, dist));
+                  if (MODE == MODE_SHADOW_ANY) {
+                     stop = true;
+                     sp = bot;
+                     break;
+                  }
+               }
             }
          }
-         ++s;
+         s += LEAF_BATCH;
          if (stop) {
             if (sp > bot) {
                --sp;
@@ -917,19 +929,44 @@ __global__ __launch_bounds__(BLOCK_THREADS) void walk_kernel(const WalkArgs a)
       add_stat(a.counters, ST_KIND_RAYS + kind, n_ray);
       add_stat(a.counters, ST_KIND_BOX + kind, n_box);
       add_stat(a.counters, ST_KIND_TRI + kind, n_tri);
-      add_stat(a.counters, ST_NODE_LANE, d_node_lane);
-      add_stat(a.counters, ST_NODE_WAVE, d_node_wave);
-      add_stat(a.counters, ST_LEAF_LANE, n_tri);
-      add_stat(a.counters, ST_LEAF_WAVE, d_leaf_wave);
-      add_stat(a.counters, ST_OUTER_WAVE, d_outer);
-      add_stat(a.counters, ST_REFILL, d_refill);
-      add_stat(a.counters, 12, d_steal);
+      if (STATS > 1) {
+         add_stat(a.counters, ST_NODE_LANE, d_node_lane);
+         add_stat(a.counters, ST_NODE_WAVE, d_node_wave);
+         add_stat(a.counters, ST_LEAF_LANE, d_leaf_lane);
+         add_stat(a.counters, ST_LEAF_WAVE, d_leaf_wave);
+         add_stat(a.counters, ST_OUTER_WAVE, d_outer);
+         add_stat(a.counters, ST_REFILL, d_refill);
+         add_stat(a.counters, 12, d_steal);
+         if (kind != 1) {
+   #pragma unroll
+            for (int q = 0; q < 8; q++) add_stat(a.counters, ST_TRIP_HIST + (kind ? 8 : 0) + q, d_hist[q]);
+         }
+         {
+            unsigned m = max(d_ray_trips_max, d_ray_trips);
+            for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned) __shfl_down((int) m, off, 64));
+            const unsigned long long any = __ballot(n_ray > 0);
+            if (lane == 0) {
+               unsigned long long *tl = (unsigned long long *) (a.counters + CNT_STATS) + ST_KIND_TIMELINE + 6 * kind;
+               atomicMax(tl + 4, (unsigned long long) m);
+               if (any) atomicAdd(tl + 5, 1ull);
+            }
+         }
+      }
       if (lane == 0) {
          const unsigned long long t_end = wall_clock64();
          unsigned long long *st = (unsigned long long *) (a.counters + CNT_STATS);
          atomicMax(st + 13, t_end - t_begin);                               // longest wave lifetime
          atomicAdd(st + 14, t_end - t_begin);                               // sum of wave lifetimes
          atomicAdd(st + 15, t_exhausted ? t_end - t_exhausted : 0ull);      // sum of time spent after the queue ran dry
+         unsigned long long *tl = st + ST_KIND_TIMELINE + 6 * kind;
+         atomicMax(tl + 0, ~t_begin);
+         if (t_exhausted) {
+            atomicMax(tl + 1, ~t_exhausted);
+            atomicMax(tl + 2, t_exhausted);
+         }
+         atomicMax(tl + 3, t_end);
+         atomicMax(st + ST_TAIL_TRIPS + 2 * (kind ? 1 : 0), (unsigned long long) d_tail_trips);
+         atomicAdd(st + ST_TAIL_TRIPS + 2 * (kind ? 1 : 0) + 1, (unsigned long long) d_tail_trips);
       }
    }
 }
@@ -1165,7 +1202,7 @@ int tunable(const char *name, int fallback)
 
 unsigned persistent_grid(int n_cus, unsigned long long max_items)
 {
-   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) tunable("MI355RT_BLOCKS_PER_CU", FETCH_DMA ? 4 : 6);   // blocks of 4 waves per CU (LDS: 25 KB, 41 KB with staging)
+   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) tunable("MI355RT_BLOCKS_PER_CU", 6);   // blocks of 4 waves per CU (LDS: 25.6 KB each)
    const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
    return (unsigned) (need < want ? (need ? need : 1ull) : want);
 }
@@ -1184,17 +1221,18 @@ unsigned bounded_grid(int n_cus, unsigned long long max_items)
 namespace {
 
 template <int MODE>
-hipError_t launch_walk(const WalkArgs &a, unsigned grid, bool stats, hipStream_t stream)
+hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, hipStream_t stream)
 {
-   if (stats) hipLaunchKernelGGL((walk_kernel<true, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
-   else hipLaunchKernelGGL((walk_kernel<false, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   if (stats_level > 1) hipLaunchKernelGGL((walk_kernel<2, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   else if (stats_level == 1) hipLaunchKernelGGL((walk_kernel<1, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   else hipLaunchKernelGGL((walk_kernel<0, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
    return hipGetLastError();
 }
 
 }   // namespace
 
 hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
-                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, hipStream_t stream)
+                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, int diag, hipStream_t stream)
 {
    WalkArgs a;
    a.sc = sc;
@@ -1213,7 +1251,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
-   return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats != 0, stream);
+   return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats ? (diag ? 2 : 1) : 0, stream);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
@@ -1261,8 +1299,9 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    const unsigned grid = persistent_grid(n_cus, max_items);
-   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, p.stats != 0, stream);
-   return launch_walk<MODE_SHADOW>(a, grid, p.stats != 0, stream);
+   const int level = p.stats ? (p.diag ? 2 : 1) : 0;
+   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream);
+   return launch_walk<MODE_SHADOW>(a, grid, level, stream);
 }
 
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream)

@@ -303,7 +303,7 @@ class Camera:
         self.hit_w = None
         self.lightingModel.setCamera(self)
 
-    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False, collect_times=False):
+    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False, collect_times=False, collect_diag=False):
         st = _abi.Settings()
         st.epsilon = RTStatics.EPSILON
         st.near_plane = RTStatics.NEAR_PLANE
@@ -320,7 +320,8 @@ class Camera:
         st.tile_size = tile_size
         st.tile_rank = tile_rank
         st.tile_world = tile_world
-        st.collect_stats = (_abi.COLLECT_COUNTS if collect_stats else 0) | (_abi.COLLECT_TIMES if collect_times else 0)
+        st.collect_stats = (_abi.COLLECT_COUNTS if collect_stats else 0) | (_abi.COLLECT_TIMES if collect_times else 0) | \
+            (_abi.COLLECT_DIAG if collect_diag else 0)
         return st
 
     def addActionListener(self, listener):
@@ -359,7 +360,7 @@ class Camera:
         return {name: {f: getattr(kp, f)[k] for f, _ in _abi.KernelProfile._fields_} for k, name in enumerate(_abi.KERNEL_NAMES)}
 
     def debug_counters(self):
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 64)()
         _abi.check(self._lib.mi355rt_debug_counters(self.scene._handle, out))
         return list(out)
 
