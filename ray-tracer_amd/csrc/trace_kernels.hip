@@ -209,6 +209,30 @@ __device__ __forceinline__ unsigned queue_push(unsigned *count, bool push)
    return base + (unsigned) __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// The same for a whole workgroup whose waves all append to ONE queue: one atomic per workgroup.  (An atomic
+// that returns a value costs a round trip to the memory side, and the queue counters are only eight words: with
+// one atomic per wave generate_kernel spent 0.6 of its 0.73 ms waiting for them.)  Every thread of the workgroup
+// must call it; s_cnt holds WAVES + 1 words.
+template <int WAVES> __device__ __forceinline__ unsigned block_queue_push(unsigned *count, bool push, unsigned *s_cnt)
+{
+   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+   const unsigned long long mask = __ballot(push);
+   if (lane == 0) s_cnt[w] = (unsigned) __popcll(mask);
+   __syncthreads();
+   unsigned before = 0, total = 0;
+#pragma unroll
+   for (int i = 0; i < WAVES; i++) {
+      const unsigned c = s_cnt[i];
+      before += i < w ? c : 0u;
+      total += c;
+   }
+   if (threadIdx.x == 0) s_cnt[WAVES] = total ? atomicAdd(count, total) : 0u;
+   __syncthreads();
+   const unsigned base = s_cnt[WAVES];
+   __syncthreads();   // s_cnt may be reused by the next call
+   return base + before + (unsigned) __popcll(mask & ((1ull << lane) - 1ull));
+}
+
 // ---------------------------------------------------------------- colour / BRDF (device)
 
 // java.lang.Math.min / max (float)
@@ -434,23 +458,25 @@ __device__ __forceinline__ void write_miss_outputs(const FrameArgs &p, long long
 
 // ---------------------------------------------------------------- generate
 // One wave = one 8x8 pixel group at one sample index j; sample slot = (group * ms + j) * 64 + lane.
-__global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs p)
+// A workgroup is GEN_WAVES consecutive waves of ONE band (workgroup b serves band b % N_BANDS, so workgroups that
+// run at the same time append to different sub-queues) and appends its rays with one atomic.
+constexpr int GEN_WAVES = 16;
+__global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArgs p)
 {
+   __shared__ unsigned s_cnt[GEN_WAVES + 1];
    const int lane = threadIdx.x & 63;
-   const long long wave = (long long) blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6);
    const int ms = p.multi_samples;
    const int n_micro = p.micro_end - p.micro_begin;
    const int per_band = (n_micro + N_BANDS - 1) / N_BANDS;
-   if (wave >= (long long) per_band * N_BANDS * ms) return;
-   // consecutive workgroups take groups from different bands: they run at the same time and would
-   // otherwise all append to one sub-queue's counter
-   const int unit = (int) (wave / ms);
-   const int local_micro = (unit % N_BANDS) * per_band + unit / N_BANDS;
-   if (local_micro >= n_micro) return;
-   const int j = (int) (wave % ms);
+   const int band = (int) (blockIdx.x % (unsigned) N_BANDS);
+   const long long wave_in_band = (long long) (blockIdx.x / (unsigned) N_BANDS) * GEN_WAVES + (threadIdx.x >> 6);
+   const int unit = (int) (wave_in_band / ms);
+   const int j = (int) (wave_in_band % ms);
+   const int local_micro = band * per_band + unit;
+   const bool wave_ok = unit < per_band && local_micro < n_micro;
    const unsigned slot = ((unsigned) local_micro * (unsigned) ms + (unsigned) j) * 64u + (unsigned) lane;
    int px, py;
-   const bool active = micro_pixel(p, p.micro_begin + local_micro, lane, px, py);
+   const bool active = micro_pixel(p, p.micro_begin + (wave_ok ? local_micro : 0), lane, px, py) && wave_ok;
    const long long pix = (long long) py * p.width + px;
 
    // RenderThread.java:39-47
@@ -484,8 +510,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void generate_kernel(const FrameArgs
       if (j == 0) write_miss_outputs(p, pix);
    }
    // the pass's 8x8 groups are cut into 8 bands (image order); each band has its own sub-queue
-   const int band = local_micro / per_band;
-   const unsigned idx = (unsigned) band * p.band_cap + queue_push(p.counters + CNT_Q0 + band, push);
+   const unsigned idx = (unsigned) band * p.band_cap + block_queue_push<GEN_WAVES>(p.counters + CNT_Q0 + band, push, s_cnt);
    if (push) store_ray(p.rays0, idx, o, d, slot, -1);
    if (p.stats) {
       add_stat(p.counters, ST_PRIMARY, active ? 1u : 0u);
@@ -979,6 +1004,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
                                                               const int32_t *hit_obj, int count_index, float *rays_next,
                                                               int next_count_index)
 {
+   __shared__ unsigned s_cnt[BLOCK_THREADS / 64 + 1];
    unsigned n_sec = 0;
    {
    const int band = (int) (blockIdx.x % (unsigned) N_BANDS);   // a workgroup serves one band (grid is a multiple of N_BANDS)
@@ -1068,10 +1094,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
       }
    }
    // a path's shadow ray and bounce ray stay in the path's band
-   const unsigned si = (unsigned) band * p.band_cap + queue_push(p.counters + CNT_SHADOW + band, push_shadow);
+   const unsigned si = (unsigned) band * p.band_cap + block_queue_push<BLOCK_THREADS / 64>(p.counters + CNT_SHADOW + band, push_shadow, s_cnt);
    if (push_shadow) p.shadow[si] = path;
    if (rays_next) {
-      const unsigned qi = (unsigned) band * p.band_cap + queue_push(p.counters + next_count_index + band, push_sec);
+      const unsigned qi = (unsigned) band * p.band_cap + block_queue_push<BLOCK_THREADS / 64>(p.counters + next_count_index + band, push_sec, s_cnt);
       if (push_sec) store_ray(rays_next, qi, sec_o, sec_d, path, sec_aux);
    }
    }
@@ -1259,7 +1285,9 @@ hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
    const unsigned long long n_micro = (unsigned long long) (p.micro_end - p.micro_begin);
    const unsigned long long waves = (n_micro + N_BANDS - 1) / N_BANDS * N_BANDS * (unsigned long long) p.multi_samples;
    if (!n_micro) return hipSuccess;
-   hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(waves * 64)), dim3(BLOCK_THREADS), 0, stream, p);
+   const unsigned long long waves_per_band = waves / N_BANDS;
+   const unsigned grid = (unsigned) ((waves_per_band + GEN_WAVES - 1) / GEN_WAVES) * N_BANDS;
+   hipLaunchKernelGGL(generate_kernel, dim3(grid), dim3(GEN_WAVES * 64), 0, stream, p);
    return hipGetLastError();
 }
 
