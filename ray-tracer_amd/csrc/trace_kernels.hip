@@ -561,6 +561,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_WAVES_PER_SIMD
 #define WALK_WAVES_PER_SIMD 6
 #endif
+#ifndef WALK_SHADOW_SPREAD
+#define WALK_SHADOW_SPREAD 64   // power of two
+#endif
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
 #endif
@@ -710,18 +713,23 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             const unsigned want_n = (unsigned) __popcll(idle);
             if (STATS > 1 && lane == 0) d_refill++;
-            unsigned base = 0, limit = 0;
+            // A band's queue of n rays is dealt out as a rows x spread matrix read down the columns: logical index L
+            // (what the cursor counts) -> ray (L % spread) * rows + L / spread.  Neighbouring rays (a grazing patch of
+            // the surface means long walks for all of them) then land in different waves instead of making one wave
+            // the launch's tail.  Shadow rays only: primary rays lose more from the lost coherence than they gain (measured).
+            constexpr unsigned SPREAD = MODE == MODE_CLOSEST ? 1u : (unsigned) WALK_SHADOW_SPREAD;
+            unsigned base = 0, rows = 0, count = 0, lo = 0;
             bool got = false;
             while (attempt < N_BANDS) {
                const unsigned rg = (unsigned) (home + attempt) % (unsigned) N_BANDS;
-               const unsigned lo = rg * a.band_cap;
-               const unsigned hi = lo + a.counters[a.count_index + rg];
+               lo = rg * a.band_cap;
+               count = a.counters[a.count_index + rg];
+               rows = (count + SPREAD - 1u) / SPREAD;
                unsigned b = 0;
                if (lane == 0) b = atomicAdd(cursors + rg, want_n);
                b = (unsigned) __builtin_amdgcn_readfirstlane((int) b);
-               if (b < hi - lo) {
-                  base = lo + b;
-                  limit = hi;
+               if (b < rows * SPREAD) {
+                  base = b;
                   got = true;
                   break;
                }
@@ -731,7 +739,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                exhausted = true;
                if (STATS) t_exhausted = wall_clock64();
             } else if (role == ROLE_IDLE) {
-               const unsigned my = base + (unsigned) __popcll(idle & lanes_below);
+               const unsigned logical = base + (unsigned) __popcll(idle & lanes_below);
+               const unsigned rel = (logical % SPREAD) * rows + logical / SPREAD;
+               const unsigned my = lo + rel;
+               const unsigned limit = logical < rows * SPREAD ? lo + count : 0u;
                if (my < limit) {
                   qi = my;
                   V3 o, d;
