@@ -78,15 +78,13 @@ __device__ __forceinline__ V3 reflect3(V3 n, V3 dir)
 
 struct Ray {
    V3 o, d, inv;
-   float abs_margin;
 };
 
-__device__ __forceinline__ void make_ray(Ray &r, V3 o, V3 d, float scene_abs_max)
+__device__ __forceinline__ void make_ray(Ray &r, V3 o, V3 d)
 {
    r.o = o;
    r.d = d;
    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-   r.abs_margin = 1e-5f * (scene_abs_max + fabsf(o.x) + fabsf(o.y) + fabsf(o.z));
 }
 
 // RTStatics.aabbIntersection (RTStatics.java:102-158) with 1/direction hoisted out (same value on
@@ -137,9 +135,9 @@ __device__ __forceinline__ float origin_box_dist2(const Ray &r, float lox, float
    return dx * dx + dy * dy + dz * dz;
 }
 
-__device__ __forceinline__ float prune_limit2(const Ray &r, float w)
+__device__ __forceinline__ float prune_limit2(const Ray &r, float w, float scene_abs_max)
 {
-   const float lim = w * 1.0001f + r.abs_margin;
+   const float lim = w * 1.0001f + 1e-5f * (scene_abs_max + fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
    return lim * lim;
 }
 
@@ -188,6 +186,12 @@ enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, 
        // rays of the LAST walker launch by trips taken: < 16, 32, 64, 128, 256, 512, 1024, more (8 slots per kind: primary 43.., shadow 51..)
        ST_TRIP_HIST = 43,
        ST_TAIL_TRIPS = 59 };   // {max, sum} of wave trips after the queue ran dry: primary 59,60; shadow 61,62
+
+// number of set bits of mask below this lane
+__device__ __forceinline__ int rank_below(unsigned long long mask)
+{
+   return (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
+}
 
 // true on exactly one of the currently active lanes
 __device__ __forceinline__ bool first_active_lane()
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
    const V3 d = normalize3(normalize3(t));   // RenderThread.java:47, then the Ray ctor (Ray.java:12)
    const V3 o = mk3(p.origin[0], p.origin[1], p.origin[2]);
    Ray r;
-   make_ray(r, o, d, p.sc.scene_abs_max);
+   make_ray(r, o, d);
 
    // Camera.java:205: object.intersects(ray) for each object; a ray that enters no root box is a miss
    bool any_root = false;
@@ -553,6 +557,7 @@ struct WalkArgs {
    int32_t stats;
    int32_t refill_min;   // refill once this many lanes are idle (or all of them)
    int32_t steal_min;    // while the queue still has rays: steal once this many lanes are idle
+   int32_t age_min;      // shadow modes: idle lanes help a ray that has been walked for this many trips at once
    int32_t both_min;     // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
 };
 
@@ -578,32 +583,40 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    const int wave_base = threadIdx.x & ~63;
    int *__restrict__ stack = s_stack + threadIdx.x;
    volatile int *list = s_list + wave_base;
-   const unsigned long long lanes_below = (1ull << lane) - 1ull;
    uint32_t *cursors = a.counters + a.cursor_index;
    const float4 *__restrict__ nodes = (const float4 *) a.sc.nodes;
    const float4 *__restrict__ tris = (const float4 *) a.sc.tris;
    const float nearp = a.sc.near_plane, farp = a.sc.far_plane, eps = a.sc.epsilon;
    const V3 light = mk3(a.light[0], a.light[1], a.light[2]);
    const int n_objs = a.sc.n_objs;
+   const float abs_max = a.sc.scene_abs_max;
 
    // wave-uniform
    const int home = (int) (blockIdx.x % (unsigned) N_BANDS);
    int attempt = 0;
    bool exhausted = false;
    // per lane
-   int role = ROLE_IDLE;
-   int owner = lane;      // the lane whose ray this lane is walking (itself unless ROLE_HELPER)
-   int pending = 0;       // ROLE_OWNER: helpers still walking parts of my current object
+   // role, owner, pending, k and mirror share one register (the kernel sits at the 80-VGPR step for 6 waves/SIMD)
+   struct {
+      unsigned role : 2, owner : 6, pending : 8;
+      int k : 8, mirror : 8;
+   } st;
+   st.role = ROLE_IDLE;
+   st.owner = lane;      // the lane whose ray this lane is walking (itself unless ROLE_HELPER)
+   st.pending = 0;       // ROLE_OWNER: helpers still walking parts of my current object
    unsigned qi = 0;
    Ray r;
-   make_ray(r, mk3(0, 0, 0), mk3(0, 0, -1), 0.0f);
-   int mirror = -1, k = -1, cur = STACK_EMPTY;
+   make_ray(r, mk3(0, 0, 0), mk3(0, 0, -1));
+   st.mirror = -1;
+   st.k = -1;
+   int cur = STACK_EMPTY;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
-   float sd = 0.0f, lim2 = 0.0f;
+   int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
+   float lim2 = 0.0f;
    float ob_w = 0.0f, best_w = 0.0f;
    int ob_slot = -1, ob_key = 0, best_slot = -1, best_obj = -1;
    bool occluded = false;
-   int s = 0, leaf0 = 0;   // current slot / first slot of the current leaf (valid while cur < 0)
+   int s = 0;   // current slot while cur < 0 (cur stays ~first slot of the leaf, which is also the leaf's rank in fold order)
    unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0;
    unsigned d_ray_trips = 0, d_ray_trips_max = 0;
    unsigned d_hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -618,37 +631,37 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       if (__ballot(cur == STACK_EMPTY) != 0ull) {
          // ---- (1) helpers that finished their subtree hand (w, slot, leaf) to the ray's owner, which
          // folds it in with the same order-independent rule the leaves use
-         unsigned long long fin = __ballot(role == ROLE_HELPER && cur == STACK_EMPTY);
+         unsigned long long fin = __ballot(st.role == ROLE_HELPER && cur == STACK_EMPTY);
          while (fin != 0ull) {
             const int h = __ffsll((unsigned long long) fin) - 1;
             fin &= fin - 1ull;
-            const int o = __shfl(owner, h, 64);
+            const int o = __shfl(st.owner, h, 64);
             const float hw = __shfl(ob_w, h, 64);
             const int hs = __shfl(ob_slot, h, 64), hk = __shfl(ob_key, h, 64);
             if (lane == o) {
-               --pending;
+               --st.pending;
                if (hs >= 0 && (ob_slot < 0 || hw < ob_w || (hw == ob_w && hk > ob_key))) {
                   ob_w = hw;
                   ob_slot = hs;
                   ob_key = hk;
-                  lim2 = fminf(lim2, prune_limit2(r, hw));
+                  lim2 = fminf(lim2, prune_limit2(r, hw, abs_max));
                }
             }
          }
-         if (role == ROLE_HELPER && cur == STACK_EMPTY) {
-            role = ROLE_IDLE;
-            owner = lane;
+         if (st.role == ROLE_HELPER && cur == STACK_EMPTY) {
+            st.role = ROLE_IDLE;
+            st.owner = lane;
          }
 
          // ---- (2) an owner whose walk of object k has ended (and whose helpers are all back): fold the
          // object's result, enter the next object or retire the ray
-         if (role == ROLE_OWNER && cur == STACK_EMPTY && pending == 0) {
-            if (k >= 0 && ob_slot >= 0) {
+         if (st.role == ROLE_OWNER && cur == STACK_EMPTY && st.pending == 0) {
+            if (st.k >= 0 && ob_slot >= 0) {
                if (MODE == MODE_CLOSEST) {
                   if ((ob_w > eps) && (best_obj < 0 || ob_w < best_w)) {   // Camera.java:208
                      best_w = ob_w;
                      best_slot = ob_slot;
-                     best_obj = k;
+                     best_obj = st.k;
                   }
                } else if (MODE == MODE_SHADOW_ANY) {
                   occluded = true;
@@ -660,23 +673,22 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   if (ob_w < distance3(P, light) + eps) occluded = true;
                }
             }
-            int nk = k + 1;
-            if (MODE == MODE_CLOSEST && nk == mirror) ++nk;
+            int nk = st.k + 1;
+            if (MODE == MODE_CLOSEST && nk == st.mirror) ++nk;
             const bool done = (nk >= n_objs) || (MODE != MODE_CLOSEST && occluded);
             if (!done) {
-               k = nk;
-               const DevObject *ob = a.sc.objs + k;
-               sd = ob->shadow_distance;
+               st.k = nk;
+               const DevObject *ob = a.sc.objs + st.k;
                ob_slot = -1;
                ob_w = 0.0f;
                ob_key = 0;
                sp = bot = 0;
-               lim2 = (MODE == MODE_CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w) : __builtin_inff();
+               lim2 = (MODE == MODE_CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max) : __builtin_inff();
                float te;
                if (STATS) n_box++;
                if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {
                   cur = ob->root_entry;   // KDTree.getChildIntersection (bounds/KDTree.java:59-65)
-                  s = leaf0 = ~cur;
+                  s = ~cur;
                }
             } else {
                if (MODE == MODE_CLOSEST) {
@@ -704,12 +716,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                } else {
                   a.mat0[4 * (size_t) qi + 3] = occluded ? 1.0f : 0.0f;
                }
-               role = ROLE_IDLE;
+               st.role = ROLE_IDLE;
             }
          }
 
          // ---- (3) idle lanes take new rays from the queue
-         const unsigned long long idle = __ballot(role == ROLE_IDLE);
+         const unsigned long long idle = __ballot(st.role == ROLE_IDLE);
          if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             const unsigned want_n = (unsigned) __popcll(idle);
             if (STATS > 1 && lane == 0) d_refill++;
@@ -738,8 +750,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             if (!got) {
                exhausted = true;
                if (STATS) t_exhausted = wall_clock64();
-            } else if (role == ROLE_IDLE) {
-               const unsigned logical = base + (unsigned) __popcll(idle & lanes_below);
+            } else if (st.role == ROLE_IDLE) {
+               const unsigned logical = base + (unsigned) rank_below(idle);
                const unsigned rel = (logical % SPREAD) * rows + logical / SPREAD;
                const unsigned my = lo + rel;
                const unsigned limit = logical < rows * SPREAD ? lo + count : 0u;
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                      const float4 r0 = q[0], r1 = q[1];
                      o = mk3(r0.x, r0.y, r0.z);
                      d = mk3(r1.x, r1.y, r1.z);
-                     mirror = (int) (short) (__float_as_int(r1.w) & 0xffff);
+                     st.mirror = (int) (short) (__float_as_int(r1.w) & 0xffff);
                   } else {
                      qi = a.shadow[my];   // the path
                      const float4 *hq = (const float4 *) a.hits0 + 2 * (size_t) qi;
@@ -759,18 +771,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                      const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z);
                      d = normalize3(normalize3(sub3(light, P)));   // RTStatics.java:619-620, then the Ray ctor
                      o = add3(P, scale3(N, eps));                  // RTStatics.offsetPosition
-                     mirror = -1;
+                     st.mirror = -1;
                   }
-                  make_ray(r, o, d, a.sc.scene_abs_max);
-                  role = ROLE_OWNER;
-                  owner = lane;
-                  pending = 0;
-                  k = -1;
+                  make_ray(r, o, d);
+                  st.role = ROLE_OWNER;
+                  st.owner = lane;
+                  st.pending = 0;
+                  st.k = -1;
                   sp = bot = 0;
                   best_obj = -1;
                   best_slot = -1;
                   best_w = 0.0f;
                   occluded = false;
+                  age = 0;
                   if (STATS) n_ray++;
                   if (STATS > 1) {
                      d_ray_trips_max = max(d_ray_trips_max, d_ray_trips);
@@ -788,37 +801,40 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // ---- (4) lanes still idle steal work inside the wave: the BOTTOM stack entry (the largest
          // pending subtree) of a busy lane, walked with a copy of that lane's ray.  Which lane walks a
          // subtree cannot change the result: the fold is order independent (see the header comment).
-         const unsigned long long thieves = __ballot(role == ROLE_IDLE);
-         const unsigned long long victims = __ballot(role != ROLE_IDLE && sp > bot);
-         if (thieves != 0ull && victims != 0ull && (exhausted || __popcll(thieves) >= a.steal_min)) {
+         const unsigned long long thieves = __ballot(st.role == ROLE_IDLE);
+         // Before the queue is dry a steal needs steal_min idle lanes (they would rather wait for a refill) -- except,
+         // for shadow rays, from a ray that has been walked for age_min trips already: those few long rays are what
+         // the launch ends up waiting for, so they get help as soon as a lane is free.
+         const bool steal_any = exhausted || __popcll(thieves) >= a.steal_min;
+         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || age >= a.age_min));
+         if (thieves != 0ull && victims != 0ull) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
-            const int v_rank = __popcll(victims & lanes_below), t_rank = __popcll(thieves & lanes_below);
+            const int v_rank = rank_below(victims), t_rank = rank_below(thieves);
             const bool is_victim = ((victims >> lane) & 1ull) != 0ull && v_rank < n_pairs;
-            const bool is_thief = role == ROLE_IDLE && t_rank < n_pairs;
+            const bool is_thief = st.role == ROLE_IDLE && t_rank < n_pairs;
             if (is_victim) list[v_rank] = lane;
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the list is written before it is read (one wave, in order)
             const int v = is_thief ? list[t_rank] : lane;
             const int v_bot = __shfl(bot, v, 64);
             const int entry = s_stack[min(v_bot, STACK_SLOTS - 1) * BLOCK_THREADS + wave_base + v];
-            const int v_owner = __shfl(owner, v, 64), v_k = __shfl(k, v, 64);
-            const float v_sd = __shfl(sd, v, 64), v_lim2 = __shfl(lim2, v, 64);
+            const int v_owner = __shfl(st.owner, v, 64), v_k = __shfl(st.k, v, 64);
+            const float v_lim2 = __shfl(lim2, v, 64);
             const float ox = __shfl(r.o.x, v, 64), oy = __shfl(r.o.y, v, 64), oz = __shfl(r.o.z, v, 64);
             const float dx = __shfl(r.d.x, v, 64), dy = __shfl(r.d.y, v, 64), dz = __shfl(r.d.z, v, 64);
             const float ix = __shfl(r.inv.x, v, 64), iy = __shfl(r.inv.y, v, 64), iz = __shfl(r.inv.z, v, 64);
-            const float v_margin = __shfl(r.abs_margin, v, 64);
+            const int v_age = __shfl(age, v, 64);
             if (is_victim) ++bot;
             if (is_thief) {
-               role = ROLE_HELPER;
-               owner = v_owner;
-               k = v_k;
-               sd = v_sd;
+               st.role = ROLE_HELPER;
+               st.owner = v_owner;
+               st.k = v_k;
                lim2 = v_lim2;
                r.o = mk3(ox, oy, oz);
                r.d = mk3(dx, dy, dz);
                r.inv = mk3(ix, iy, iz);
-               r.abs_margin = v_margin;
+               age = v_age;
                cur = entry;
-               s = leaf0 = ~cur;
+               s = ~cur;
                sp = bot = 0;
                ob_slot = -1;
                ob_w = 0.0f;
@@ -829,14 +845,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             while (tm != 0ull) {
                const int t = __ffsll((unsigned long long) tm) - 1;
                tm &= tm - 1ull;
-               const int o = __shfl(owner, t, 64);
-               if (lane == o) ++pending;
+               const int o = __shfl(st.owner, t, 64);
+               if (lane == o) ++st.pending;
             }
          }
          // prune limits found on the owner's side reach its helpers here
-         lim2 = fminf(lim2, __shfl(lim2, owner, 64));
+         lim2 = fminf(lim2, __shfl(lim2, st.owner, 64));
 
-         if (__ballot(role != ROLE_IDLE) == 0ull) {
+         if (__ballot(st.role != ROLE_IDLE) == 0ull) {
             if (exhausted) break;
             continue;
          }
@@ -845,7 +861,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       // ---- one step per lane: an internal node (C) or one face of a leaf (D).  A trip that ran both
       // paths for a handful of lanes each would spend most of its issue slots on masked-off lanes, so
       // the minority state sits a trip out unless it is populous too (it becomes the majority soon).
-      if (STATS > 1 && role == ROLE_OWNER) d_ray_trips++;
+      if (STATS > 1 && st.role == ROLE_OWNER) d_ray_trips++;
+      ++age;
       const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
       const bool in_leaf = cur < 0;
       const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
@@ -911,7 +928,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          } else {
             cur = STACK_EMPTY;
          }
-         s = leaf0 = ~cur;
+         s = ~cur;
       }
 
       if (is_leaf) {
@@ -929,12 +946,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                if (STATS) n_tri++;
                float u, v, dist;
                V3 P;
-               if (tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist) && (dist > sd) &&
-                   (ob_slot < 0 || dist < ob_w || (dist == ob_w && leaf0 > ob_key))) {
+               if (tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist) && (dist > a.sc.objs[st.k].shadow_distance) &&
+                   (ob_slot < 0 || dist < ob_w || (dist == ob_w && ~cur > ob_key))) {
                   ob_w = dist;
                   ob_slot = s + j;
-                  ob_key = leaf0;
-                  lim2 = fminf(lim2, prune_limit2(r, dist));
+                  ob_key = ~cur;
+                  lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
                   if (MODE == MODE_SHADOW_ANY) {
                      stop = true;
                      sp = bot;
@@ -951,7 +968,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             } else {
                cur = STACK_EMPTY;
             }
-            s = leaf0 = ~cur;
+            s = ~cur;
          }
       }
    }
@@ -1288,6 +1305,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
+   a.age_min = tunable("MI355RT_AGE_MIN_CLOSEST", 1 << 30);
    return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats ? (diag ? 2 : 1) : 0, stream);
 }
 
@@ -1337,6 +1355,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
+   a.age_min = tunable("MI355RT_AGE_MIN", 4);
    const unsigned grid = persistent_grid(n_cus, max_items);
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream);
