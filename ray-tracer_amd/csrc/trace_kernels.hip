@@ -557,6 +557,7 @@ struct WalkArgs {
    int32_t stats;
    int32_t refill_min;   // refill once this many lanes are idle (or all of them)
    int32_t steal_min;    // while the queue still has rays: steal once this many lanes are idle
+   int32_t tail_steal_min;   // once the queue is dry: steal with this many idle lanes
    int32_t age_min;      // shadow modes: idle lanes help a ray that has been walked for this many trips at once
    int32_t both_min;     // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
 };
@@ -635,9 +636,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          while (fin != 0ull) {
             const int h = __ffsll((unsigned long long) fin) - 1;
             fin &= fin - 1ull;
-            const int o = __shfl(st.owner, h, 64);
-            const float hw = __shfl(ob_w, h, 64);
-            const int hs = __shfl(ob_slot, h, 64), hk = __shfl(ob_key, h, 64);
+            // h is wave-uniform: v_readlane (a few cycles) instead of a ds_bpermute round trip per value
+            const int o = __builtin_amdgcn_readlane((int) st.owner, h);
+            const float hw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ob_w), h));
+            const int hs = __builtin_amdgcn_readlane(ob_slot, h), hk = __builtin_amdgcn_readlane(ob_key, h);
             if (lane == o) {
                --st.pending;
                if (hs >= 0 && (ob_slot < 0 || hw < ob_w || (hw == ob_w && hk > ob_key))) {
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // Before the queue is dry a steal needs steal_min idle lanes (they would rather wait for a refill) -- except,
          // for shadow rays, from a ray that has been walked for age_min trips already: those few long rays are what
          // the launch ends up waiting for, so they get help as soon as a lane is free.
-         const bool steal_any = exhausted || __popcll(thieves) >= a.steal_min;
+         const bool steal_any = (exhausted && __popcll(thieves) >= a.tail_steal_min) || __popcll(thieves) >= a.steal_min;
          const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || age >= a.age_min));
          if (thieves != 0ull && victims != 0ull) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             while (tm != 0ull) {
                const int t = __ffsll((unsigned long long) tm) - 1;
                tm &= tm - 1ull;
-               const int o = __shfl(st.owner, t, 64);
+               const int o = __builtin_amdgcn_readlane((int) st.owner, t);
                if (lane == o) ++st.pending;
             }
          }
@@ -866,7 +868,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
       const bool in_leaf = cur < 0;
       const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
-      const bool both = n_node >= a.both_min && n_leaf >= a.both_min;
+      // once the queue is dry what counts is how soon the last rays end, not issue slots: nobody sits out
+      const bool both = exhausted || (n_node >= a.both_min && n_leaf >= a.both_min);
       const bool is_node = in_node && (both || n_node >= n_leaf);
       const bool is_leaf = in_leaf && (both || n_leaf > n_node);
       // One fetch per lane per trip, issued up front for every lane so that the latencies overlap: a node lane
@@ -1304,6 +1307,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.stats = stats;
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
+   a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    a.age_min = tunable("MI355RT_AGE_MIN_CLOSEST", 1 << 30);
    return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats ? (diag ? 2 : 1) : 0, stream);
@@ -1354,6 +1358,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.stats = p.stats;
    a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
+   a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    a.age_min = tunable("MI355RT_AGE_MIN", 4);
    const unsigned grid = persistent_grid(n_cus, max_items);
