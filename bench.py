@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="tuning aid (single process): render only rank 0's tiles of an N-rank run; the line is not a bench result")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
     args = ap.parse_args()
 
@@ -84,8 +86,10 @@ def main():
     sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev)
     stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream
 
+    tile_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+
     def step(stats=False, times=False):
-        cam.render_device(frame, stream=stream, tile_rank=rank, tile_world=world, tile_size=tiles.DEFAULT_TILE,
+        cam.render_device(frame, stream=stream, tile_rank=rank, tile_world=tile_world, tile_size=tiles.DEFAULT_TILE,
                           collect_stats=stats, collect_times=times)
 
     # counted, not assumed: one instrumented frame

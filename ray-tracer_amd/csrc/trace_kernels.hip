@@ -1257,9 +1257,22 @@ int tunable(const char *name, int fallback)
    return v && *v ? atoi(v) : fallback;
 }
 
-unsigned persistent_grid(int n_cus, unsigned long long max_items)
+// Workgroups per CU of a persistent launch.  Every launch ends on its longest rays, and the more waves are in
+// flight the more long rays are started late, so a short queue gets fewer waves (measured on 1/8 of the bench
+// frame: primary 1.24 ms at 3 per CU against 1.36 at 6 and 2.09 at 1; shadow 0.38 at 1 against 0.58 at 4).  The
+// queue length is only known on the device; `slots` (samples of the pass) stands in for it.
+int blocks_per_cu_for(const char *env, int n_cus, unsigned long long slots, unsigned long long slots_per_lane, int lo, int hi)
 {
-   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) tunable("MI355RT_BLOCKS_PER_CU", 6);   // blocks of 4 waves per CU (LDS: 25.6 KB each)
+   const int forced = tunable(env, 0);
+   if (forced > 0) return forced;
+   const unsigned long long per = (unsigned long long) n_cus * BLOCK_THREADS * slots_per_lane;
+   const long long want = (long long) ((slots + per / 2) / per);
+   return (int) (want < lo ? lo : (want > hi ? hi : want));
+}
+
+unsigned persistent_grid(int n_cus, unsigned long long max_items, int blocks_per_cu)
+{
+   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) blocks_per_cu;   // blocks of 4 waves per CU (LDS: 25.6 KB each)
    const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
    return (unsigned) (need < want ? (need ? need : 1ull) : want);
 }
@@ -1310,7 +1323,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    a.age_min = tunable("MI355RT_AGE_MIN_CLOSEST", 1 << 30);
-   return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items), stats ? (diag ? 2 : 1) : 0, stream);
+   return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, 6)), stats ? (diag ? 2 : 1) : 0, stream);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
@@ -1361,7 +1374,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    a.age_min = tunable("MI355RT_AGE_MIN", 4);
-   const unsigned grid = persistent_grid(n_cus, max_items);
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream);
    return launch_walk<MODE_SHADOW>(a, grid, level, stream);

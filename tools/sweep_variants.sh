@@ -6,7 +6,7 @@ for spec in "$@"; do
   lib=$PWD/build/variants/$name.so
   [ "$name" = base ] && lib=$PWD/ray-tracer_amd/libmi355rt.so
   extra=$(echo "$envs" | tr ',' ' ')
-  env MI355RT_LIB=$lib MI355RT_BLOCKS_PER_CU=$bpc $extra timeout -k 10 120 python bench.py --no-cpu-baseline --steps 10 --warmup 2 > gpurun_out/sweep_$name.json 2> gpurun_out/sweep_$name.err || { echo "$spec FAILED"; tail -3 gpurun_out/sweep_$name.err; exit 1; }
+  env MI355RT_LIB=$lib MI355RT_BLOCKS_PER_CU=$bpc $extra timeout -k 10 120 python bench.py --no-cpu-baseline --steps 10 --warmup 2 $BENCH_EXTRA > gpurun_out/sweep_$name.json 2> gpurun_out/sweep_$name.err || { echo "$spec FAILED"; tail -3 gpurun_out/sweep_$name.err; exit 1; }
   python - <<PY
 import json
 d=json.load(open("gpurun_out/sweep_$name.json"))
