@@ -68,29 +68,44 @@ def unpack_tiles(packed, pix, rgb, hit_w, hit_id):
 
 
 class TileSharder:
-    """Pre-computes the index tensors once; gather() is the per-frame exchange step."""
+    """Pre-computes every index tensor once; gather() is the per-frame exchange step and launches a fixed, small
+    number of kernels (no boolean masks, so no device-to-host synchronisation inside the timed step)."""
 
     def __init__(self, width, height, rank, world, tile=DEFAULT_TILE, device="cpu"):
         self.width, self.height, self.rank, self.world, self.tile = width, height, rank, world, tile
         self.device = torch.device(device)
         self.n_slots = max_owned(width, height, world, tile)
+        tt = tile * tile
         self.my_pix = tile_pixels(width, height, owned_tiles(width, height, rank, world, tile), tile, self.device)
-        self.all_pix = None
-        if rank == 0:
-            self.all_pix = [tile_pixels(width, height, owned_tiles(width, height, r, world, tile), tile, self.device)
-                            for r in range(world)]
-            self.recv = [torch.empty((self.n_slots, tile * tile, CHANNELS), dtype=torch.float32, device=self.device)
-                         for _ in range(world)]
+        self.n_mine = self.my_pix.shape[0]
+        self.my_safe = self.my_pix.clamp(min=0).reshape(-1)
+        self.send = torch.zeros((self.n_slots, tt, CHANNELS), dtype=torch.float32, device=self.device)
+        if rank == 0 and world > 1:
+            self.recv_all = torch.empty((world, self.n_slots, tt, CHANNELS), dtype=torch.float32, device=self.device)
+            self.recv = [self.recv_all[r] for r in range(world)]
+            src, dst = [], []
+            for r in range(1, world):   # rank 0's own tiles are already in place
+                pix = tile_pixels(width, height, owned_tiles(width, height, r, world, tile), tile, self.device).reshape(-1)
+                keep = torch.nonzero(pix >= 0).squeeze(1)
+                src.append(keep + r * self.n_slots * tt)
+                dst.append(pix[keep])
+            self.src = torch.cat(src)
+            self.dst = torch.cat(dst)
 
     def gather(self, rgb, hit_w, hit_id):
         """rgb [H,W,3] f32, hit_w [H,W] f32, hit_id [H,W] i32: this rank's frame (owned tiles valid).
         On return rank 0's tensors hold the whole frame."""
         if self.world == 1:
             return
-        mine = pack_tiles(rgb, hit_w, hit_id, self.my_pix, self.n_slots)
+        n, tt = self.n_mine, self.tile * self.tile
+        self.send[:n, :, 0:3] = rgb.reshape(-1, 3).index_select(0, self.my_safe).reshape(n, tt, 3)
+        self.send[:n, :, 3] = hit_w.reshape(-1).index_select(0, self.my_safe).reshape(n, tt)
+        self.send[:n, :, 4] = hit_id.reshape(-1).index_select(0, self.my_safe).view(torch.float32).reshape(n, tt)
         if self.rank == 0:
-            dist.gather(mine, gather_list=self.recv, dst=0)
-            for r in range(1, self.world):
-                unpack_tiles(self.recv[r], self.all_pix[r], rgb, hit_w, hit_id)
+            dist.gather(self.send, gather_list=self.recv, dst=0)
+            got = self.recv_all.reshape(-1, CHANNELS).index_select(0, self.src)
+            rgb.reshape(-1, 3).index_copy_(0, self.dst, got[:, 0:3])
+            hit_w.reshape(-1).index_copy_(0, self.dst, got[:, 3])
+            hit_id.reshape(-1).index_copy_(0, self.dst, got[:, 4].contiguous().view(torch.int32))
         else:
-            dist.gather(mine, gather_list=None, dst=0)
+            dist.gather(self.send, gather_list=None, dst=0)
