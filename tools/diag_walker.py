@@ -16,7 +16,8 @@ for lm, name in ((rt.LightingModel(), "primary only"), (rt.PhongLightingModel(li
     cam = rt.Camera(scene, spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
     rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     frame = rt._abi.Frame(rgb.data_ptr(), None, None, None, None)
-    cam.render_device(frame, collect_stats=True)   # light: same occupancy as the production kernel
+    for _ in range(3):   # the third frame runs with the longest-first order from the second
+        cam.render_device(frame, collect_stats=True)   # light: same occupancy as the production kernel
     torch.cuda.synchronize()
     light_d = cam.debug_counters()
     cam.render_device(frame, collect_diag=True)
