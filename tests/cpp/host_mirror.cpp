@@ -1,0 +1,98 @@
+// host_mirror.cpp -- drives libmi355rt.so through the C++ host mirror (include/mi355rt.hpp) the way
+// RayTracer.java / RayTracerInterface.java drive the reference; the pytest wrappers compare its output with the
+// oracle (tests/test_cpp_host.py).
+//   host_mirror abi
+//   host_mirror render <mesh.ply> <width> <height> <multiSamples> <seed> <fov> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "mi355rt.hpp"
+
+using namespace mi355rt;
+
+static int run_abi()
+{
+   std::printf("abi %d devices %d\n", mi355rt_abi_version(), mi355rt_device_count());
+   Light light({ 0.f, 100.f, 100.f }, { 0.3f, 0.3f, 0.3f }, { 0.5f, 0.5f, 0.9f });
+   ColorInformation white({ 1.f, 1.f, 1.f });
+   ReflectionMaterial mirror({ 0.9f, 0.9f, 1.0f });
+   BRDFMaterial felt(3, { 0.2f, 0.8f, 0.3f });
+   if (white.abi().shininess != 20.0f || mirror.abi().shininess != 100.0f || felt.abi().brdf_id != 3 ||
+       mirror.abi().kind != MI355RT_MAT_REFLECTION || felt.abi().kind != MI355RT_MAT_BRDF) {
+      std::printf("material defaults wrong\n");
+      return 1;
+   }
+   try {
+      TriangleMesh missing("/nonexistent/mesh.ply", white, true);
+      std::printf("no error for a missing file\n");
+      return 1;
+   } catch (const Error &e) {
+      if (e.code != MI355RT_E_IO) {
+         std::printf("wrong code %d\n", e.code);
+         return 1;
+      }
+      std::printf("missing file -> E_IO: %s\n", e.what());
+   }
+   // without a HIP device the library must refuse, not fall back
+   if (mi355rt_device_count() == 0) {
+      TriangleMesh tri({ 0, 0, 0, 1, 0, 0, 0, 1, 0 }, { 0, 1, 2 }, white, true);
+      PhongLightingModel model(light, { &tri });
+      try {
+         Scene scene({ &tri }, light, { 0, 0, 0 }, model, 15.0f);
+         std::printf("scene built without a device\n");
+         return 1;
+      } catch (const Error &e) {
+         if (e.code != MI355RT_E_DEVICE) return 1;
+         std::printf("no device -> E_DEVICE\n");
+      }
+   }
+   std::printf("ABI_OK\n");
+   return 0;
+}
+
+static int run_render(char **argv)
+{
+   const std::string ply = argv[2];
+   const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), ms = std::atoi(argv[5]);
+   const unsigned long long seed = std::strtoull(argv[6], nullptr, 10);
+   const float fov = (float) std::atof(argv[7]);
+   Light light({ 0.f, 100.f, 100.f }, { 0.3f, 0.3f, 0.3f }, { 0.5f, 0.5f, 0.9f });     // RayTracer.java:106
+   TriangleMesh mesh(ply, ColorInformation({ 0.9f, 0.9f, 0.9f }), true);
+   PhongLightingModel model(light, { &mesh });
+   Scene scene({ &mesh }, light, { 0.f, 0.f, 0.f }, model, fov);
+   Camera camera(scene, ms, 1, RTStatics::NEAR_PLANE, W, H);
+   camera.rngSeed = seed;
+   int fired = 0;
+   camera.addActionListener([&](int id, const char *what) { fired += (id == 1 && std::strcmp(what, "finished") == 0) ? 1 : 0; });
+   camera.createImage();
+   if (fired != 1) {
+      std::printf("listener fired %d times\n", fired);
+      return 1;
+   }
+   FILE *f = std::fopen(argv[8], "wb");
+   if (!f) return 1;
+   const float header[8] = { camera.cam.origin[0], camera.cam.origin[1], camera.cam.origin[2], camera.cam.viewport_w, camera.cam.viewport_h,
+                             RTStatics::EPSILON(), (float) W, (float) H };
+   std::fwrite(header, sizeof(float), 8, f);
+   std::fwrite(camera.rowMajorPixels().data(), sizeof(float), (size_t) 3 * W * H, f);
+   std::fwrite(camera.hitId.data(), sizeof(int32_t), (size_t) W * H, f);
+   std::fwrite(camera.hitW.data(), sizeof(float), (size_t) W * H, f);
+   std::fclose(f);
+   std::printf("RENDER_OK %dx%d pixel(0,0)=%g\n", W, H, camera.getPixel(0, 0)[0]);
+   return 0;
+}
+
+int main(int argc, char **argv)
+{
+   try {
+      if (argc >= 2 && std::strcmp(argv[1], "abi") == 0) return run_abi();
+      if (argc >= 9 && std::strcmp(argv[1], "render") == 0) return run_render(argv);
+   } catch (const std::exception &e) {
+      std::printf("exception: %s\n", e.what());
+      return 2;
+   }
+   std::printf("usage: host_mirror abi | render <ply> <W> <H> <ms> <seed> <fov> <out.bin>\n");
+   return 64;
+}

@@ -1,0 +1,53 @@
+"""The C++ host mirror (include/mi355rt.hpp) driven the way RayTracer.java drives the reference:
+tests/cpp/host_mirror (built by __graft_entry__.build() / make -C tests/cpp)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BINARY = os.path.join(HERE, "cpp", "host_mirror")
+
+
+def _run(*args):
+    if not os.path.exists(BINARY):
+        pytest.fail("tests/cpp/host_mirror is not built: run __graft_entry__.build()")
+    return subprocess.run([BINARY, *map(str, args)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+
+
+def test_cpp_mirror_builds_and_reports_errors():
+    """No GPU needed: material defaults, a missing PLY raises E_IO, and without a device scene creation is refused
+    (MI355RT_E_DEVICE) rather than served by some fallback."""
+    r = _run("abi")
+    assert r.returncode == 0, r.stdout
+    assert "ABI_OK" in r.stdout and "E_IO" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_frame_matches_oracle(rt, orc, tmp_path):
+    """TriangleMesh(ply) -> Scene -> Camera.createImage() in C++ against the oracle on the same PLY."""
+    from helpers import compare_frames
+    v, i = rt.meshgen.blob(12000, span=0.156, stretch=(1.0, 0.99, 0.78), seed=1)
+    ply = str(tmp_path / "mesh.ply")
+    rt.meshgen.write_ply(ply, v, i, binary=True)
+    W, H, ms, seed, fov = 200, 150, 2, 77, 15.0
+    out = str(tmp_path / "frame.bin")
+    r = _run("render", ply, W, H, ms, seed, fov, out)
+    assert r.returncode == 0 and "RENDER_OK" in r.stdout, r.stdout
+    raw = np.fromfile(out, dtype=np.float32)
+    header, body = raw[:8], raw[8:]
+    rgb = body[: 3 * W * H].reshape(H, W, 3)
+    hid = body[3 * W * H: 4 * W * H].view(np.int32).reshape(H, W)
+    hw = body[4 * W * H: 5 * W * H].reshape(H, W)
+    ov, oi, on = orc.ply_load(ply)
+    osc = orc.OracleScene([(ov, oi, on, orc.material(diffuse=(0.9, 0.9, 0.9)))])
+    ocam = osc.camera((0, 0, 0), fov, 0.01, W, H)
+    np.testing.assert_array_equal(np.array(ocam.origin[:], dtype=np.float32), header[:3])
+    assert np.float32(osc.epsilon()) == header[5]
+    ost = orc.settings(epsilon=osc.epsilon(), ms=ms, lighting=1, seed=seed)
+    o = osc.render(ocam, ost, n_threads=8)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(rgb, hid, hw, o)
+    assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
+    assert (hid >= 0).mean() > 0.1
+    osc.close()
