@@ -188,6 +188,17 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
                        const float *directions, int32_t *hit_id, int32_t *hit_obj, float *hit_w, float *hit_point,
                        float *hit_normal);
 
+/* ---- 8-bit images (next row: SURVEY.md 8f rank 3) ----------------------------------------- */
+
+/* Replaces the image half of Camera.setPixel (Camera.java:103-107; normalized == 0) and
+ * Camera.updateNormalizedImage (Camera.java:217-263; normalized != 0) for a finished f32 frame: rgb is
+ * row-major width*height*3 (what mi355rt_render returns), argb_out gets width*height Color.getRGB() values.
+ * Host buffers; runs on `device` (-1: current). */
+int mi355rt_image_argb8(const float *rgb, int32_t width, int32_t height, int normalized, uint32_t *argb_out, int32_t device);
+/* The same on device buffers of the current device, asynchronous on hip_stream; minmax_scratch = 2 device words. */
+int mi355rt_image_argb8_device(const float *rgb_dev, int32_t width, int32_t height, int normalized, uint32_t *argb_dev,
+                               uint32_t *minmax_scratch, void *hip_stream);
+
 /* ---- loader (next row: SURVEY.md 8f rank 1) ---------------------------------------------- */
 
 /* Replaces the TriangleMesh constructor's parse (sceneObjects/TriangleMesh.java:23-94,128-197).

@@ -13,6 +13,7 @@
  */
 #include "rt_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -1121,6 +1122,49 @@ void orc_normalize(float v[3])
    v3 a = { v[0], v[1], v[2] };
    a = v3normalize(a);
    v[0] = a.x; v[1] = a.y; v[2] = a.z;
+}
+
+/* new Color(bound(0,1,r), bound(0,1,g), bound(0,1,b)).getRGB(): java.awt.Color(float,float,float) rounds each
+ * component with (int) (c * 255 + 0.5); RTStatics.bound (RTStatics.java:384-386) */
+static uint32_t pack_color(float r, float g, float b)
+{
+   const float c[3] = { jmin(1.0f, jmax(0.0f, r)), jmin(1.0f, jmax(0.0f, g)), jmin(1.0f, jmax(0.0f, b)) };
+   uint32_t out = 0xFF000000u;
+   int k;
+   for (k = 0; k < 3; k++) out |= ((uint32_t) (int) ((double) (c[k] * 255.0f) + 0.5) & 255u) << (16 - 8 * k);
+   return out;
+}
+
+/* normalized == 0: the 8-bit image Camera.setPixel keeps (Camera.java:103-107).
+ * normalized != 0: Camera.updateNormalizedImage (Camera.java:217-263): min / max of the HSV value over the pixels
+ * without a NaN, then value := (value - min) / (max - min), back to RGB, packed.  rgb is row-major W*H*3. */
+void orc_image_argb8(const float *rgb, int32_t width, int32_t height, int normalized, uint32_t *out)
+{
+   const size_t n = (size_t) width * (size_t) height;
+   float lo = FLT_MAX, hi = -FLT_MAX;
+   size_t i;
+   if (normalized) {
+      for (i = 0; i < n; i++) {
+         const float *c = rgb + 3 * i;
+         float hsv[3];
+         if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) continue;
+         rgb_to_hsv(c, hsv);
+         lo = jmin(lo, hsv[2]);
+         hi = jmax(hi, hsv[2]);
+      }
+   }
+   for (i = 0; i < n; i++) {
+      const float *c = rgb + 3 * i;
+      if (normalized) {
+         float hsv[3], o[3];
+         rgb_to_hsv(c, hsv);
+         hsv[2] = (hsv[2] - lo) / (hi - lo);
+         hsv_to_rgb(hsv, o);
+         out[i] = pack_color(o[0], o[1], o[2]);
+      } else {
+         out[i] = pack_color(c[0], c[1], c[2]);
+      }
+   }
 }
 
 void orc_rgb_to_hsv(const float rgb[3], float hsv[3]) { rgb_to_hsv(rgb, hsv); }

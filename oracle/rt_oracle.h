@@ -105,6 +105,7 @@ int orc_aabb_intersection(const float o[3], const float d[3], const float minmax
 int orc_intersects_triangle(const float o[3], const float d[3], const float p[9], const float n[9], float eps, float out[7]);
 void orc_reflection_direction(const float n[3], const float dir[3], float out[3]);
 void orc_normalize(float v[3]);
+void orc_image_argb8(const float *rgb, int32_t width, int32_t height, int normalized, uint32_t *out);
 void orc_rgb_to_hsv(const float rgb[3], float hsv[3]);
 void orc_hsv_to_rgb(const float hsv[3], float rgb[3]);
 void orc_remap_angles(const float in2[2], const float out2[2], float out3[3]);

@@ -87,6 +87,8 @@ PROTOTYPES = {
     "mi355rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
     "mi355rt_frame_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mi355rt_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile), C.c_int]),
+    "mi355rt_image_argb8": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int, c_uint32_p, C.c_int32]),
+    "mi355rt_image_argb8_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355rt_trace_rays": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_uint64, c_float_p, c_float_p, c_int32_p,
                                      c_int32_p, c_float_p, c_float_p, c_float_p]),
     "mi355rt_debug_arith": (C.c_int, [C.c_uint64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),

@@ -783,6 +783,44 @@ int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
    return MI355RT_OK;
 }
 
+int mi355rt_image_argb8_device(const float *rgb_dev, int32_t width, int32_t height, int normalized, uint32_t *argb_dev,
+                               uint32_t *minmax_scratch, void *hip_stream)
+{
+   if (!rgb_dev || !argb_dev || (normalized && !minmax_scratch)) return fail(MI355RT_E_ARG, "null argument");
+   if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+   int device = 0, cus = 256;
+   HIP_TRY(hipGetDevice(&device));
+   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+   HIP_TRY(launch_image(rgb_dev, (unsigned long long) width * (unsigned long long) height, normalized, minmax_scratch, argb_dev, cus,
+                        (hipStream_t) hip_stream));
+   return MI355RT_OK;
+}
+
+int mi355rt_image_argb8(const float *rgb, int32_t width, int32_t height, int normalized, uint32_t *argb_out, int32_t device)
+{
+   if (!rgb || !argb_out) return fail(MI355RT_E_ARG, "null argument");
+   if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+   int n_dev = 0;
+   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
+   if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(MI355RT_E_DEVICE, "hipGetDevice failed");
+   if (device >= n_dev) return fail(MI355RT_E_ARG, "device ordinal out of range");
+   DeviceScope scope(device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   const size_t n = (size_t) width * (size_t) height;
+   float *d_rgb = nullptr;
+   uint32_t *d_out = nullptr;   // n pixels + 2 words of min / max
+   hipError_t e = hipMalloc((void **) &d_rgb, n * 3 * sizeof(float));
+   if (e == hipSuccess) e = hipMalloc((void **) &d_out, (n + 2) * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+   int rc = MI355RT_OK;
+   if (e == hipSuccess) rc = mi355rt_image_argb8_device(d_rgb, width, height, normalized, d_out, d_out + n, nullptr);
+   if (e == hipSuccess && rc == MI355RT_OK) e = hipMemcpy(argb_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+   if (d_rgb) (void) hipFree(d_rgb);
+   if (d_out) (void) hipFree(d_out);
+   if (e != hipSuccess) return hip_fail(e, "mi355rt_image_argb8");
+   return rc;
+}
+
 int mi355rt_kernel_profile(mi355rt_scene *scene, mi355rt_kernel_times *out, int reset)
 {
    if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");

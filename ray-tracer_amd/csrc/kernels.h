@@ -15,6 +15,7 @@ hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const 
 hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_resolve(const FrameArgs &p, hipStream_t stream);
+hipError_t launch_image(const float *rgb, unsigned long long n_pixels, int normalized, unsigned *minmax2, unsigned *argb, int n_cus, hipStream_t stream);
 hipError_t launch_batch_pack(const TraceBatchArgs &a, hipStream_t stream);
 hipError_t launch_batch_unpack(const TraceBatchArgs &a, hipStream_t stream);
 hipError_t launch_arith_probe(unsigned long long n, const float *a, const float *b, float *out_div, float *out_sqrt,

@@ -1196,6 +1196,78 @@ __global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const FrameArgs 
    }
 }
 
+// ---------------------------------------------------------------- 8-bit images (Camera.image, Camera.getNormalizedImage)
+__device__ __forceinline__ unsigned pack_color(float r, float g, float b)   // new Color(bound(r), bound(g), bound(b)).getRGB()
+{
+   const float br = jminf(1.0f, jmaxf(0.0f, r)), bg = jminf(1.0f, jmaxf(0.0f, g)), bb = jminf(1.0f, jmaxf(0.0f, b));
+   const unsigned ir = (unsigned) (int) ((double) (br * 255.0f) + 0.5);
+   const unsigned ig = (unsigned) (int) ((double) (bg * 255.0f) + 0.5);
+   const unsigned ib = (unsigned) (int) ((double) (bb * 255.0f) + 0.5);
+   return 0xFF000000u | ((ir & 255u) << 16) | ((ig & 255u) << 8) | (ib & 255u);
+}
+// floats as unsigned keys whose order is the floats' order (-0 below +0, as Math.min / Math.max have it)
+__device__ __forceinline__ unsigned float_key(float f)
+{
+   const unsigned u = __float_as_uint(f);
+   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// Camera.updateNormalizedImage, first loop (Camera.java:226-241): min and max of the HSV value over the pixels
+// without a NaN.  mm[0] = key of the min (start: 0xffffffff), mm[1] = key of the max (start: 0).
+__global__ __launch_bounds__(BLOCK_THREADS) void image_minmax_kernel(const float *rgb, unsigned long long n, unsigned *mm)
+{
+   __shared__ unsigned s_lo[BLOCK_THREADS / 64], s_hi[BLOCK_THREADS / 64];
+   unsigned lo = 0xffffffffu, hi = 0u;
+   for (unsigned long long i = (unsigned long long) blockIdx.x * BLOCK_THREADS + threadIdx.x; i < n; i += (unsigned long long) gridDim.x * BLOCK_THREADS) {
+      const float c[3] = { rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+      if (c[0] != c[0] || c[1] != c[1] || c[2] != c[2]) continue;
+      float hsv[3];
+      rgb_to_hsv(c, hsv);
+      const unsigned k = float_key(hsv[2]);
+      lo = min(lo, k);
+      hi = max(hi, k);
+   }
+   for (int off = 32; off > 0; off >>= 1) {
+      lo = min(lo, (unsigned) __shfl_down((int) lo, off, 64));
+      hi = max(hi, (unsigned) __shfl_down((int) hi, off, 64));
+   }
+   if ((threadIdx.x & 63) == 0) {
+      s_lo[threadIdx.x >> 6] = lo;
+      s_hi[threadIdx.x >> 6] = hi;
+   }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      for (int w = 1; w < BLOCK_THREADS / 64; w++) {
+         lo = min(lo, s_lo[w]);
+         hi = max(hi, s_hi[w]);
+      }
+      atomicMin(mm, lo);
+      atomicMax(mm + 1, hi);
+   }
+}
+
+// normalized == 0: Camera.setPixel's 8-bit image (Camera.java:103-107); else the second loop of
+// updateNormalizedImage (Camera.java:246-258): value := (value - min) / (max - min), back to RGB, packed.
+__global__ __launch_bounds__(BLOCK_THREADS) void image_pack_kernel(const float *rgb, unsigned long long n, const unsigned *mm, int normalized,
+                                                                   unsigned *argb)
+{
+   const unsigned long long i = (unsigned long long) blockIdx.x * BLOCK_THREADS + threadIdx.x;
+   if (i >= n) return;
+   float c[3] = { rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2] };
+   if (normalized) {
+      const float lo = key_float(mm[0]), hi = key_float(mm[1]);
+      float hsv[3], out[3];
+      rgb_to_hsv(c, hsv);
+      hsv[2] = (hsv[2] - lo) / (hi - lo);
+      hsv_to_rgb(hsv, out);
+      c[0] = out[0];
+      c[1] = out[1];
+      c[2] = out[2];
+   }
+   argb[i] = pack_color(c[0], c[1], c[2]);
+}
+
 // ---------------------------------------------------------------- ray batches (mi355rt_trace_rays)
 __global__ void batch_pack_kernel(const TraceBatchArgs a)
 {
@@ -1392,6 +1464,20 @@ hipError_t launch_resolve(const FrameArgs &p, hipStream_t stream)
    const unsigned long long micro = (unsigned long long) (p.micro_end - p.micro_begin);
    if (!micro) return hipSuccess;
    hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(micro * 64)), dim3(BLOCK_THREADS), 0, stream, p);
+   return hipGetLastError();
+}
+
+hipError_t launch_image(const float *rgb, unsigned long long n_pixels, int normalized, unsigned *minmax2, unsigned *argb, int n_cus, hipStream_t stream)
+{
+   if (!n_pixels) return hipSuccess;
+   if (normalized) {
+      const unsigned init[2] = { 0xffffffffu, 0u };
+      hipError_t e = hipMemcpyAsync(minmax2, init, sizeof(init), hipMemcpyHostToDevice, stream);
+      if (e != hipSuccess) return e;
+      const unsigned long long want = (unsigned long long) n_cus * 4ull, need = (n_pixels + BLOCK_THREADS - 1) / BLOCK_THREADS;
+      hipLaunchKernelGGL(image_minmax_kernel, dim3((unsigned) (need < want ? need : want)), dim3(BLOCK_THREADS), 0, stream, rgb, n_pixels, minmax2);
+   }
+   hipLaunchKernelGGL(image_pack_kernel, dim3(blocks_for(n_pixels)), dim3(BLOCK_THREADS), 0, stream, rgb, n_pixels, minmax2, normalized, argb);
    return hipGetLastError();
 }
 

@@ -342,6 +342,17 @@ class Camera:
             listener(self, 1, "finished")
         self.listeners = []
 
+    def getImage(self, normalized=False):
+        """Camera.image (normalized=False) / Camera.getNormalizedImage() as uint32 ARGB [H, W] from the last frame."""
+        H, W = self.screenHeight, self.screenWidth
+        out = np.empty((H, W), dtype=np.uint32)
+        _abi.check(self._lib.mi355rt_image_argb8(_fp(self._rgb_rows), W, H, 1 if normalized else 0,
+                                                 out.ctypes.data_as(_abi.c_uint32_p), -1))
+        return out
+
+    def getNormalizedImage(self):
+        return self.getImage(normalized=True)
+
     def render_device(self, frame, stream=None, **kw):
         """mi355rt_render_device: `frame` is an _abi.Frame of device pointers; asynchronous."""
         st = self.settings(**kw)

@@ -103,6 +103,8 @@ def lib():
         L.orc_rng_next_float.restype = C.c_float
         L.orc_compute_normals.argtypes = [fp, C.c_uint32, ip, C.c_uint32, fp]
         L.orc_compute_normals.restype = None
+        L.orc_image_argb8.argtypes = [fp, C.c_int32, C.c_int32, C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_image_argb8.restype = None
         L.orc_ply_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(fp), C.POINTER(fp),
                                    C.POINTER(ip), ip]
         L.orc_ply_free.argtypes = [C.c_void_p]

@@ -196,3 +196,27 @@ def test_empty_and_degenerate_meshes(rt, orc):
     close = np.abs(cam._rgb_rows - o["rgb"]) <= 1e-3 * np.maximum(np.abs(o["rgb"]), 1e-3)
     assert (both_nan | close).all()
     pair.close()
+
+
+def test_8bit_images_match_oracle(rt, orc):
+    """Camera.image and Camera.getNormalizedImage() (Camera.java:103-107, 217-263) from a rendered frame, and from
+    a synthetic frame with negative, > 1 and NaN-scrubbed (zero) pixels: every packed pixel identical."""
+    import ctypes as C
+    scene, _, _, _ = _scene(rt, 8000, name="bunny")
+    cam = rt.Camera(scene, 2, 1, rt.RTStatics.NEAR_PLANE, 160, 120, rng_seed=4)
+    cam.createImage()
+    frames = [cam._rgb_rows]
+    rs = np.random.RandomState(8)
+    synth = (rs.standard_normal((90, 130, 3)) * 0.8 + 0.4).astype(np.float32)
+    synth[5, 7] = 0.0
+    frames.append(synth)
+    for rgb in frames:
+        H, W = rgb.shape[:2]
+        cam._rgb_rows, cam.screenHeight, cam.screenWidth = np.ascontiguousarray(rgb), H, W
+        for normalized in (False, True):
+            got = cam.getImage(normalized)
+            exp = np.zeros((H, W), dtype=np.uint32)
+            orc.lib().orc_image_argb8(orc.P(np.ascontiguousarray(rgb)), W, H, 1 if normalized else 0, exp.ctypes.data_as(C.POINTER(C.c_uint32)))
+            np.testing.assert_array_equal(got, exp)
+            assert len(np.unique(got)) > 50
+    scene.close()

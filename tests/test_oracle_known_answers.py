@@ -196,3 +196,22 @@ def test_tie_rule_last_leaf_first_slot(orc):
     r = s.trace(st, [[0.25, 0.25, 1.0]], [[0, 0, -1]])
     assert r["face"][0] == 0
     s.close()
+
+
+def test_image_packing_and_normalisation(orc):
+    """Camera.image: Color(bound(c)).getRGB() = (int)(c*255+0.5) per channel, alpha 255 (Camera.java:103-107);
+    Camera.updateNormalizedImage stretches the HSV value to [0,1] over the frame (Camera.java:217-263)."""
+    import numpy as np
+    rgb = np.array([[[0.0, 0.5, 1.0], [-0.3, 1.7, 0.25]],
+                    [[0.2, 0.2, 0.2], [0.6, 0.3, 0.1]]], dtype=np.float32)
+    out = np.zeros((2, 2), dtype=np.uint32)
+    orc.lib().orc_image_argb8(orc.P(rgb), 2, 2, 0, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert out[0, 0] == 0xFF0080FF          # 0.5*255+0.5 = 128
+    assert out[0, 1] == 0xFF00FF40          # clamped; 0.25*255+0.5 = 64.25 -> 64
+    assert out[1, 0] == 0xFF333333
+    # normalised: values (max channel) are 1.0, 1.7, 0.2, 0.6 -> min 0.2, max 1.7; grey 0.2 -> 0, the 1.7 pixel -> value 1
+    orc.lib().orc_image_argb8(orc.P(rgb), 2, 2, 1, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    assert out[1, 0] == 0xFF000000
+    assert (out[0, 1] >> 8) & 0xFF == 0xFF
+    g = (np.float32(0.6) - np.float32(0.2)) / (np.float32(1.7) - np.float32(0.2))      # red channel of the last pixel = its value
+    assert (out[1, 1] >> 16) & 0xFF == int(np.float64(np.float32(g * np.float32(255.0))) + 0.5)
