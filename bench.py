@@ -172,8 +172,8 @@ def main():
     dom_rays = max(kc["rays"] / n_launch, 1.0)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": {"walk_primary": "walk_kernel<false,MODE_CLOSEST> (primary rays)",
-                           "walk_shadow": "walk_kernel<false,MODE_SHADOW_ANY> (shadow rays)"}.get(dom, dom),
+                "kernel": {"walk_primary": "walk_kernel<0,MODE_CLOSEST> (primary rays)",
+                           "walk_shadow": "walk_kernel<0,MODE_SHADOW_ANY> (shadow rays)"}.get(dom, dom),
                 "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "rays_per_launch": dom_rays, "bytes_per_ray": round(algo_bytes / dom_rays, 1),
                 "box_tests_per_ray": round(kc["box_tests"] / n_launch / dom_rays, 2),
@@ -190,8 +190,8 @@ def main():
         "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: Dragon stand-in (seeded procedural blob, %d faces) %dx%d, %d spp, Phong, "
-                               "primary+shadow" % (idx.shape[0], W, H, args.spp),
+        "config": {"workload": "%s stand-in (seeded procedural blob, %d faces) %dx%d, %d spp, Phong, primary+shadow"
+                               % ("configs[1]: Dragon" if args.model == "dragon" and not args.faces else args.model, idx.shape[0], W, H, args.spp),
                    "rays_per_frame": int(rays_per_frame), "primary": int(primary), "shadow": int(shadow),
                    "tile": tiles.DEFAULT_TILE, "parallelism": "tiles%d" % world,
                    "hierarchy": {k: scene.object_info(0)[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")},

@@ -220,3 +220,60 @@ def test_8bit_images_match_oracle(rt, orc):
             np.testing.assert_array_equal(got, exp)
             assert len(np.unique(got)) > 50
     scene.close()
+
+
+def _compare_at_sampled_pixels(cam, o, rtol=1e-3):
+    """The oracle rendered every k-th pixel (hit_id stays -2 elsewhere): ids and w bit-exact, radiance within rtol there."""
+    m = o["hit_id"] != -2
+    assert m.sum() > 1000
+    assert np.array_equal(cam.hit_id.T[m], o["hit_id"][m]), int((cam.hit_id.T[m] != o["hit_id"][m]).sum())
+    assert np.array_equal(cam.hit_w.T[m].view(np.uint32), o["hit_w"][m].view(np.uint32))
+    denom = np.maximum(np.abs(o["rgb"][m]), 1e-3)
+    rel = np.abs(cam._rgb_rows[m] - o["rgb"][m]) / denom
+    assert rel.max() <= rtol, float(rel.max())
+    return float((o["hit_id"][m] >= 0).mean())
+
+
+def test_buddha_config_brdf_full_size(rt, orc):
+    """BASELINE configs[2]: Buddha-class mesh (1,087,716 faces), 1920x1080, measured-BRDF material under Phong,
+    orientation (180,0,0), fov 10 (RayTracer.java:125-128).  The whole frame on the GPU; the oracle (its table
+    search is slow on a CPU) checks every 7th pixel."""
+    from helpers import synthetic_brdf_tables
+    cfg = rt.meshgen.STANFORD["buddha"]
+    v, i = rt.meshgen.stanford_standin("buddha")
+    assert i.shape[0] == 1087716
+    tables = synthetic_brdf_tables()
+    rt.BRDFMaterial.setTables(*tables)
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+    mesh = rt.TriangleMesh((v, i), rt.BRDFMaterial(3, (0.2, 0.8, 0.3)), True)
+    scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"])
+    cam = rt.Camera(scene, 1, 2, rt.RTStatics.NEAR_PLANE, 1920, 1080, rng_seed=5)
+    cam.createImage()
+    osc = orc.OracleScene([(v, i, None, orc.material(kind=1, diffuse=(0.2, 0.8, 0.3), brdf_id=3))])
+    osc.set_brdf(*tables)
+    ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, 1920, 1080)
+    ost = orc.settings(epsilon=osc.epsilon(), ms=1, brdf_samples=2, lighting=1, seed=5, light_origin=light.origin,
+                       light_emission=light.emission, light_ambient=light.ambient)
+    o = osc.render(ocam, ost, n_threads=16, pixel_stride=7)
+    frac = _compare_at_sampled_pixels(cam, o)
+    assert 0.05 < frac < 0.95
+    osc.close()
+    scene.close()
+
+
+def test_thai_class_mirror_4k_two_passes(rt, orc):
+    """The shape of BASELINE configs[3]/[4] at a size the oracle can follow: a 2-million-face mesh of span 400
+    (EPSILON = 1e-3, Scene.java:36) with ReflectionMaterial over a floor, 3840x2160, 3 spp = 24.9 M samples in two
+    passes with mirror bounces; the oracle checks every 211th pixel."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(2000000, span=400.0, stretch=(0.59, 1.0, 0.52), seed=4)
+    fv, fi = rt.meshgen.quad(-205.0, 230.0)
+    pair = Pair([(v, i, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))), (fv, fi, None, rt.ColorInformation((0.8, 0.3, 0.2)))],
+                orientation=(0, -20, 0), fov=30.0)
+    assert np.float32(pair.eps) == np.float32(1e-3)
+    cam, ocam, ost = pair.cameras(3840, 2160, ms=3, seed=21)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=211, want_stats=True)
+    frac = _compare_at_sampled_pixels(cam, o)
+    assert frac > 0.2 and o["stats"]["secondary_rays"] > 10000
+    pair.close()
