@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 1
+#define MI355RT_ABI_VERSION 2   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials */
 
 enum {
    MI355RT_OK = 0,
@@ -34,7 +34,17 @@ enum {
 
 /* materials/ColorInformation.java:15-37, materials/BRDFMaterial.java:47-51,158-167,
  * materials/ReflectionMaterial.java:10-24 */
-enum { MI355RT_MAT_COLOR = 0, MI355RT_MAT_BRDF = 1, MI355RT_MAT_REFLECTION = 2 };
+enum { MI355RT_MAT_COLOR = 0, MI355RT_MAT_BRDF = 1, MI355RT_MAT_REFLECTION = 2,
+       MI355RT_MAT_REFRACTION = 3,     /* materials/RefractionMaterial.java:29-95 (mi355rt_material_ext.refraction_index) */
+       MI355RT_MAT_CHECKERBOARD = 4 }; /* materials/CheckerboardMaterial.java:21-49 (mi355rt_material_ext.checker_*) */
+/* Scene.objects entries (next row: SURVEY.md 8f rank 2): bounds/KDTree.java over a TriangleMesh (0),
+ * sceneObjects/Sphere.java:29-112 inside its bounds/BoundingSphere.java:29-102 (1),
+ * sceneObjects/Plane.java:28-154 inside its bounds/AxisAlignedBoundingBox.java (2) */
+enum { MI355RT_OBJ_MESH = 0, MI355RT_OBJ_SPHERE = 1, MI355RT_OBJ_PLANE = 2 };
+/* Guard with no counterpart in the reference (like max_mirror_bounces): a path carries at most this many pending
+ * RefractionMaterial absorption terms (RefractionMaterial.java:43-53); a further RefractionMaterial hit on that
+ * path answers with its diffuse colour, as SceneObject.getColor does at its depth cut-off. */
+#define MI355RT_MAX_REFRACTION_TERMS 8
 /* lighting/LightingModel.java:13-15 (0), lighting/PhongLightingModel.java:18-54 (1) */
 enum { MI355RT_LIGHTING_PLAIN = 0, MI355RT_LIGHTING_PHONG = 1 };
 
@@ -55,6 +65,22 @@ typedef struct {
 } mi355rt_mesh_desc;
 
 typedef struct {
+   float refraction_index;                     /* RefractionMaterial.refractionIndex (INDEX_OF_GLASS 1.52f ...) */
+   float checker_color1[3], checker_color2[3]; /* CheckerboardMaterial.color1 / color2 components */
+   float checker_cell[3];                      /* cellWidth, cellHeight, cellDepth */
+} mi355rt_material_ext;
+
+/* one entry of Scene.objects */
+typedef struct {
+   uint32_t kind;             /* MI355RT_OBJ_* */
+   mi355rt_mesh_desc mesh;    /* MESH: the arrays.  Every kind: mesh.material is the object's ColorInformation */
+   mi355rt_material_ext ext;  /* read for MI355RT_MAT_REFRACTION / MI355RT_MAT_CHECKERBOARD */
+   float center[3], radius;   /* SPHERE: new Sphere(radius, origin, colorInfo) (Sphere.java:15-22) */
+   float corners[12];         /* PLANE: new Plane(corners, colorInfo) (Plane.java:28-76), 3 floats per corner */
+   uint32_t n_corners;        /* 3 or 4 */
+} mi355rt_object_desc;
+
+typedef struct {
    int32_t max_depth;    /* RTStatics.MAX_DEPTH = 20    (RTStatics.java:25) */
    int32_t max_children; /* RTStatics.MAX_CHILDREN = 5  (RTStatics.java:24) */
    int32_t use_kdtree;   /* the GUI's KD-tree checkbox / computeKDTree (bounds/KDNode.java:40) */
@@ -73,7 +99,8 @@ typedef struct {
 typedef struct {
    float epsilon;               /* RTStatics.EPSILON as set by the Scene ctor (Scene.java:35-36) */
    float near_plane, far_plane; /* RTStatics.NEAR_PLANE 0.01f / FAR_PLANE 3000f (RTStatics.java:19-20) */
-   int32_t max_recursion_depth; /* RTStatics.MAX_RECURSION_DEPTH (unused by mesh objects: KDTree.getColor has no cut-off) */
+   int32_t max_recursion_depth; /* RTStatics.MAX_RECURSION_DEPTH = 5: SceneObject.getColor's cut-off for spheres and planes
+                                 * (SceneObject.java:65-67); unused by mesh objects: KDTree.getColor has no cut-off */
    int32_t multi_samples;       /* Camera.multiSamples */
    int32_t brdf_samples;        /* Camera.brdfSamples */
    int32_t lighting_model;      /* MI355RT_LIGHTING_* */
@@ -105,6 +132,7 @@ enum {
    MI355RT_K_WALK_SHADOW = 4,    /* RTStatics.shadowIntersects */
    MI355RT_K_PHONG = 5,          /* PhongLightingModel.getPixelColor */
    MI355RT_K_RESOLVE = 6,        /* RenderThread's average over the samples, pixel write */
+   MI355RT_K_ANALYTIC = 7,       /* Sphere / Plane intersections folded into the walkers' results (launched only when the scene has any) */
    MI355RT_N_KERNELS = 8
 };
 
@@ -120,8 +148,8 @@ typedef struct {
 typedef struct {
    float *rgb;        /* width*height*3, unclamped f32 after the NaN scrub (Camera.java:96-101) */
    uint32_t *argb8;   /* width*height, Color(r,g,b).getRGB() as in Camera.image (Camera.java:103-107) */
-   int32_t *hit_id;   /* width*height, face index within its mesh for sample 0, -1 = miss */
-   int32_t *hit_obj;  /* width*height, mesh index for sample 0, -1 = miss */
+   int32_t *hit_id;   /* width*height, face index within its mesh for sample 0 (0 for a sphere or plane), -1 = miss */
+   int32_t *hit_obj;  /* width*height, object index for sample 0, -1 = miss */
    float *hit_w;      /* width*height, IntersectionInformation.w for sample 0 */
 } mi355rt_frame;
 
@@ -134,6 +162,12 @@ typedef struct mi355rt_scene mi355rt_scene;
  * (Scene.java:21-33): builds the reference's hierarchy, flattens it and uploads it to HBM. */
 int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts,
                          mi355rt_scene **out);
+/* The same for any mix of meshes, spheres and planes in Scene.objects order (RayTracer.getWhittedObjects /
+ * getCornellBox, RayTracer.java:155-235).  Spheres and planes are intersected analytically
+ * (Sphere.java:29-112, Plane.java:87-154) behind their own bounding tests (BoundingSphere.java:29-102,
+ * RTStatics.aabbIntersection); planes with colinear corners fail with MI355RT_E_ARG as Plane.java:56-58 throws. */
+int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_objects, const mi355rt_build_opts *opts,
+                                 mi355rt_scene **out);
 void mi355rt_scene_destroy(mi355rt_scene *scene);
 
 /* Replaces BRDFMaterial.brdfDirections / brdfWeights (materials/BRDFMaterial.java:33,43): takes the

@@ -88,11 +88,17 @@ typedef struct kdnode {
 } kdnode;
 
 typedef struct {
+   uint32_t kind;         /* ORC_OBJ_* */
    float *vertices, *normals;
    int32_t *indices;
    uint32_t n_vertices, n_faces;
    orc_material mat;
-   float mm[2][3];        /* KDTree.minMax (KDTree.java:32-44) */
+   orc_material_ext ext;
+   v3 center;             /* Sphere.origin / BoundingSphere.origin */
+   float radius;
+   float pA, pB, pC, pD;  /* Plane.A..D (Plane.java:37-51) */
+   v3 pnormal;            /* Plane.normal (Plane.java:53-54) */
+   float mm[2][3];        /* KDTree.minMax (KDTree.java:32-44); BoundingSphere.getMinMax; the Plane's AxisAlignedBoundingBox */
    float shadow_distance; /* KDTree.java:46 */
    kdnode *root;
    uint64_t n_nodes, n_leaves, n_leaf_slots;
@@ -259,6 +265,177 @@ static int intersects_triangle(v3 rO, v3 rD, const float *P0, const float *P1, c
    return 1;
 }
 
+/* ---------------------------------------------------------------- analytic primitives */
+
+/* RTStatics.leastPositive RTStatics.java:82-100 */
+static float least_positive(float i, float j)
+{
+   float ret;
+   if (i < 0 && j < 0) ret = -1;
+   else if (i < 0 && j > 0) ret = j;
+   else if (i > 0 && j < 0) ret = i;
+   else if (i < j) ret = i;
+   else ret = j;
+   return ret;
+}
+
+/* The quadratic of Sphere.getIntersection (Sphere.java:38-99) and BoundingSphere.intersects
+ * (BoundingSphere.java:34-95); they differ only in the first near-origin threshold (0.01 against
+ * RTStatics.EPSILON).  Math.pow(x, 2) of a float x is exact in double, so x * x in double restates it.
+ * Returns w, or -1 where the reference returns null / false. */
+static float sphere_quadratic(v3 origin, v3 direction, v3 center, float radius, double first_threshold)
+{
+   const float a = (float) ((double) direction.x * (double) direction.x + (double) direction.y * (double) direction.y +
+                            (double) direction.z * (double) direction.z);
+   const float b = 2 * (direction.x * (origin.x - center.x) + direction.y * (origin.y - center.y) + direction.z * (origin.z - center.z));
+   const float ex = origin.x - center.x, ey = origin.y - center.y, ez = origin.z - center.z;
+   const float c = (float) ((double) ex * (double) ex + (double) ey * (double) ey + (double) ez * (double) ez - (double) radius * (double) radius);
+   const float b24c = (float) ((double) b * (double) b) - 4 * c;
+   const float wplus = (float) ((double) -b + sqrt((double) b24c)) / (2 * a);
+   const float wminus = (float) ((double) -b - sqrt((double) b24c)) / (2 * a);
+   float w;
+   if (b24c < 0) return -1;
+   w = least_positive(wplus, wminus);
+   if (w <= 0) return -1;
+   if (w == wplus) {
+      const float xn = origin.x + direction.x * wplus, yn = origin.y + direction.y * wplus, zn = origin.z + direction.z * wplus;
+      const float xd = origin.x - xn, yd = origin.y - yn, zd = origin.z - zn;
+      const float nDist = (float) sqrt((double) (xd * xd + yd * yd + zd * zd));
+      if (((double) nDist < first_threshold) && (wminus > 0)) w = wminus;
+      else if (((double) nDist < first_threshold) && (wminus < 0)) return -1;
+   } else if (w == wminus) {
+      const float xm = origin.x + direction.x * wminus, ym = origin.y + direction.y * wminus, zm = origin.z + direction.z * wminus;
+      const float xd = origin.x - xm, yd = origin.y - ym, zd = origin.z - zm;
+      const float mDist = (float) sqrt((double) (xd * xd + yd * yd + zd * zd));
+      if (((double) mDist < 0.01) && (wplus > 0)) w = wplus;
+      else if (((double) mDist < 0.01) && (wplus < 0)) return -1;
+   }
+   return (w > 0) ? w : -1;
+}
+
+/* BoundingSphere.intersects bounds/BoundingSphere.java:29-102 (the ray is not advanced) */
+static int bounding_sphere_intersects(const ray *r, v3 center, float radius, float eps)
+{
+   return sphere_quadratic(r->origin, r->dir, center, radius, (double) eps) > 0;
+}
+
+/* Sphere.getIntersection sceneObjects/Sphere.java:29-112; out = {x,y,z,nx,ny,nz,w} */
+static int sphere_intersection(const ray *r, v3 center, float radius, float eps, float out[7])
+{
+   const v3 origin = v3add(r->origin, v3scale(r->dir, eps * 2)); /* Sphere.java:30-33 */
+   const float w = sphere_quadratic(origin, r->dir, center, radius, 0.01);
+   v3 p, n;
+   if (!(w > 0)) return 0;
+   p = v3add(v3scale(r->dir, w), origin); /* Sphere.java:102-104 */
+   n = v3normalize(v3sub(p, center));
+   out[0] = p.x; out[1] = p.y; out[2] = p.z;
+   out[3] = n.x; out[4] = n.y; out[5] = n.z;
+   out[6] = w; /* offsetDistance is 0 (Sphere.java:35) */
+   return 1;
+}
+
+/* Plane constructor sceneObjects/Plane.java:28-76; returns 0, or -1 for colinear corners (:56-58) */
+static int plane_setup(object *o, const float *cn, uint32_t n_corners)
+{
+   float c[4][3];
+   uint32_t i;
+   int k;
+   for (i = 0; i < 4; i++)
+      for (k = 0; k < 3; k++) c[i][k] = cn[3 * (i < n_corners ? i : 2) + k]; /* :60-63 a triangle repeats its third corner */
+   o->pA = c[0][1] * (c[1][2] - c[2][2]) + c[1][1] * (c[2][2] - c[0][2]) + c[2][1] * (c[0][2] - c[1][2]);
+   o->pB = c[0][2] * (c[1][0] - c[2][0]) + c[1][2] * (c[2][0] - c[0][0]) + c[2][2] * (c[0][0] - c[1][0]);
+   o->pC = c[0][0] * (c[1][1] - c[2][1]) + c[1][0] * (c[2][1] - c[0][1]) + c[2][0] * (c[0][1] - c[1][1]);
+   o->pD = -(c[0][0] * (c[1][1] * c[2][2] - c[2][1] * c[1][2]) + c[1][0] * (c[2][1] * c[0][2] - c[0][1] * c[2][2]) +
+             c[2][0] * (c[0][1] * c[1][2] - c[1][1] * c[0][2]));
+   o->pnormal.x = o->pA; o->pnormal.y = o->pB; o->pnormal.z = o->pC;
+   o->pnormal = v3normalize(o->pnormal);
+   if ((o->pA == 0) && (o->pB == 0) && (o->pC == 0)) return -1;
+   for (k = 0; k < 3; k++) {
+      o->mm[0][k] = jmin(c[0][k], jmin(c[1][k], jmin(c[2][k], c[3][k])));
+      o->mm[1][k] = jmax(c[0][k], jmax(c[1][k], jmax(c[2][k], c[3][k])));
+   }
+   return 0;
+}
+
+/* Plane.getIntersection sceneObjects/Plane.java:87-154 */
+static int plane_intersection(const object *o, const ray *r, float eps, float out[7])
+{
+   const v3 origin = v3add(r->origin, v3scale(r->dir, eps * 2)); /* :88-91 */
+   const v3 dir = r->dir;
+   v3 pn = o->pnormal;
+   float vD = v3dot(pn, dir);
+   if (vD > eps) {
+      pn = v3scale(pn, -1);
+      vD = v3dot(pn, dir);
+   }
+   if ((vD <= -eps) || (vD >= eps)) {
+      const float t = -(o->pA * origin.x + o->pB * origin.y + o->pC * origin.z + o->pD) / (o->pA * dir.x + o->pB * dir.y + o->pC * dir.z);
+      if (t > -eps) {
+         v3 rD = dir, pI;
+         if (vD > -eps) { rD.x = -rD.x; rD.y = -rD.y; rD.z = -rD.z; }
+         pI.x = origin.x + rD.x * t;
+         pI.y = origin.y + rD.y * t;
+         pI.z = origin.z + rD.z * t;
+         /* Plane.pointInPolygon :143-145 */
+         if ((pI.x >= o->mm[0][0] - eps) && (pI.x <= o->mm[1][0] + eps) && (pI.y >= o->mm[0][1] - eps) && (pI.y <= o->mm[1][1] + eps) &&
+             (pI.z >= o->mm[0][2] - eps) && (pI.z <= o->mm[1][2] + eps)) {
+            const v3 temp = v3sub(pI, origin);
+            out[0] = pI.x; out[1] = pI.y; out[2] = pI.z;
+            out[3] = pn.x; out[4] = pn.y; out[5] = pn.z;
+            out[6] = (float) sqrt((double) (temp.x * temp.x + temp.y * temp.y + temp.z * temp.z)); /* Vector3f.length() */
+            return 1;
+         }
+      }
+   }
+   return 0;
+}
+
+/* RefractionMaterial.getRefractionDirection materials/RefractionMaterial.java:61-95 */
+static v3 refraction_direction(v3 normal, v3 in_dir, float refraction_index)
+{
+   const float aether = 1.00029f; /* INDEX_OF_AIR :12,20 */
+   v3 surface_normal = normal, out;
+   double n;
+   double cosI = (double) v3dot(surface_normal, in_dir);
+   double snell_root;
+   if (cosI <= 0) {
+      n = (double) (refraction_index / aether);
+      cosI = -cosI;
+   } else {
+      n = (double) (aether / refraction_index);
+      surface_normal = v3scale(surface_normal, -1.0f);
+   }
+   snell_root = 1.0 - n * n * (1.0 - cosI * cosI);
+   if (snell_root < 0) {
+      out = reflection_direction(surface_normal, in_dir);
+   } else {
+      out = v3scale(in_dir, (float) n);
+      out = v3add(out, v3scale(surface_normal, (float) (n * cosI - sqrt(snell_root))));
+      out = v3normalize(out);
+   }
+   return out;
+}
+
+/* CheckerboardMaterial.getMaterialColor materials/CheckerboardMaterial.java:21-49 */
+static void checker_color(const float mm[2][3], v3 p, const orc_material_ext *e, float out[3])
+{
+   const float xSpan = mm[1][0] - mm[0][0], ySpan = mm[1][1] - mm[0][1], zSpan = mm[1][2] - mm[0][2];
+   const float xDist = p.x - mm[0][0], yDist = p.y - mm[0][1], zDist = p.z - mm[0][2];
+   int32_t xCell, yCell, zCell;
+   if ((xDist < 0) || (yDist < 0) || (zDist < 0) || (xDist > xSpan) || (yDist > ySpan) || (zDist > zSpan)) {
+      out[0] = out[1] = out[2] = 0.0f;
+      return;
+   }
+   xCell = jd2i(floor((double) (xDist / e->checker_cell[0])));
+   yCell = jd2i(floor((double) (yDist / e->checker_cell[1])));
+   zCell = jd2i(floor((double) (zDist / e->checker_cell[2])));
+   if (((xCell % 2 == 0) && (yCell % 2 == 0) && (zCell % 2 == 0)) || ((xCell % 2 == 1) && (yCell % 2 == 0) && (zCell % 2 == 1)) ||
+       ((xCell % 2 == 0) && (yCell % 2 == 1) && (zCell % 2 == 1)))
+      memcpy(out, e->checker_color1, sizeof(float) * 3);
+   else
+      memcpy(out, e->checker_color2, sizeof(float) * 3);
+}
+
 /* ---------------------------------------------------------------- hierarchy build */
 
 typedef struct {
@@ -421,6 +598,36 @@ static int kdtree_child_intersection(ctx *c, uint32_t obj, const ray *r, hitinfo
    return 1;
 }
 
+/* BoundingVolume.intersects: KDTree / AxisAlignedBoundingBox -> RTStatics.aabbIntersection, BoundingSphere.java:29-102 */
+static int object_intersects(ctx *c, const object *o, const ray *r)
+{
+   if (o->kind == ORC_OBJ_SPHERE) return bounding_sphere_intersects(r, o->center, o->radius, c->st->epsilon);
+   if (o->kind == ORC_OBJ_MESH) c->stats.box_tests++;
+   return aabb_intersection(r, (const float(*)[3]) o->mm, c->st->near_plane, c->st->far_plane);
+}
+
+/* BoundingVolume.getChildIntersection: KDTree.java:59-65, BoundingSphere.java:24-26 (tests itself again),
+ * AxisAlignedBoundingBox.java:26-28 (no test) */
+static int object_child_intersection(ctx *c, uint32_t obj, const ray *r, hitinfo *out)
+{
+   const object *o = &c->scene->objs[obj];
+   float v[7];
+   if (o->kind == ORC_OBJ_MESH) return kdtree_child_intersection(c, obj, r, out);
+   if (o->kind == ORC_OBJ_SPHERE) {
+      if (!bounding_sphere_intersects(r, o->center, o->radius, c->st->epsilon)) return 0;
+      if (!sphere_intersection(r, o->center, o->radius, c->st->epsilon, v)) return 0;
+   } else {
+      if (!plane_intersection(o, r, c->st->epsilon, v)) return 0;
+   }
+   out->point.x = v[0]; out->point.y = v[1]; out->point.z = v[2];
+   out->normal.x = v[3]; out->normal.y = v[4]; out->normal.z = v[5];
+   out->w = v[6];
+   out->obj = (int32_t) obj;
+   out->face = 0;
+   out->r = *r;
+   return 1;
+}
+
 /* Camera.getClosestIntersection Camera.java:193-215 (Ray ctor Ray.java:9-13 normalises direction again) */
 static int closest_intersection(ctx *c, int32_t mirror_obj, v3 origin, v3 direction, const v3 *normal, hitinfo *closest)
 {
@@ -433,9 +640,8 @@ static int closest_intersection(ctx *c, int32_t mirror_obj, v3 origin, v3 direct
    r.dir = v3normalize(direction);
    for (i = 0; i < c->scene->n_objs; i++) {
       if (mirror_obj >= 0 && (uint32_t) mirror_obj == i) continue;
-      c->stats.box_tests++;
-      if (!aabb_intersection(&r, (const float(*)[3]) c->scene->objs[i].mm, c->st->near_plane, c->st->far_plane)) continue;
-      if (kdtree_child_intersection(c, i, &r, &temp)) {
+      if (!object_intersects(c, &c->scene->objs[i], &r)) continue;
+      if (object_child_intersection(c, i, &r, &temp)) {
          if ((temp.w > c->st->epsilon) && (!have || (temp.w < closest->w))) {
             *closest = temp;
             have = 1;
@@ -457,7 +663,7 @@ static int shadow_intersects(ctx *c, const hitinfo *info)
    r.dir = v3normalize(d); /* Ray ctor */
    c->stats.shadow_rays++;
    for (i = 0; i < c->scene->n_objs; i++) {
-      if (kdtree_child_intersection(c, i, &r, &sh) && sh.w > c->st->epsilon) {
+      if (object_child_intersection(c, i, &r, &sh) && sh.w > c->st->epsilon) {
          const float light_distance = distance3(sh.point, light);
          if (sh.w < light_distance + c->st->epsilon) return 1;
       }
@@ -615,13 +821,19 @@ static float brdf_luminocity(const orc_scene *sc, int32_t brdf_id, int32_t brdf_
 
 /* ---------------------------------------------------------------- materials / lighting */
 
-static void material_color(ctx *c, const hitinfo *info, int bounces, float out[3]);
+static void material_color(ctx *c, const hitinfo *info, int bounces, int n_terms, float out[3]);
 
-/* KDTree.getColor bounds/KDTree.java:77-80 -> ColorInformation.getMaterialColor (no depth cut-off) */
-static void material_color(ctx *c, const hitinfo *info, int bounces, float out[3])
+/* BoundingVolume.getColor: KDTree.getColor bounds/KDTree.java:77-80 has no depth cut-off; BoundingSphere /
+ * AxisAlignedBoundingBox forward to SceneObject.getColor sceneObjects/SceneObject.java:64-70, which has one.
+ * `bounces` is the reference's `depth`; n_terms counts the RefractionMaterial terms pending on this path. */
+static void material_color(ctx *c, const hitinfo *info, int bounces, int n_terms, float out[3])
 {
    const object *o = &c->scene->objs[info->obj];
    const v3 light = { c->st->light_origin[0], c->st->light_origin[1], c->st->light_origin[2] };
+   if (o->kind != ORC_OBJ_MESH && bounces >= c->st->max_recursion_depth) { /* SceneObject.java:65-67 */
+      memcpy(out, o->mat.diffuse, sizeof(float) * 3);
+      return;
+   }
    switch (o->mat.kind) {
    case ORC_MAT_BRDF: {
       /* BRDFMaterial.getMaterialColor materials/BRDFMaterial.java:158-167 */
@@ -645,10 +857,40 @@ static void material_color(ctx *c, const hitinfo *info, int bounces, float out[3
       if (!closest_intersection(c, info->obj, info->point, refl, &info->normal, &m)) {
          memcpy(out, c->st->light_ambient, sizeof(float) * 3);
       } else {
-         material_color(c, &m, bounces + 1, out);
+         material_color(c, &m, bounces + 1, n_terms, out);
       }
       return;
    }
+   case ORC_MAT_REFRACTION: {
+      /* RefractionMaterial.getMaterialColor materials/RefractionMaterial.java:29-59 */
+      hitinfo m;
+      v3 dir;
+      int entering, k;
+      if (bounces >= c->st->max_mirror_bounces || n_terms >= ORC_MAX_REFRACTION_TERMS) { /* guards */
+         memcpy(out, o->mat.diffuse, sizeof(float) * 3);
+         return;
+      }
+      dir = refraction_direction(info->normal, info->r.dir, o->ext.refraction_index);
+      c->stats.secondary_rays++;
+      if (!closest_intersection(c, info->obj, info->point, dir, &info->normal, &m)) {
+         memcpy(out, c->st->light_ambient, sizeof(float) * 3);
+         return;
+      }
+      entering = v3dot(info->normal, info->r.dir) <= 0.0f;
+      material_color(c, &m, bounces + 1, n_terms + (entering ? 1 : 0), out);
+      if (entering) {
+         const float distance = distance3(info->point, m.point);
+         for (k = 0; k < 3; k++) {
+            float col = o->mat.diffuse[k];
+            col *= 0.15f * -distance;
+            out[k] = (float) ((double) out[k] + exp((double) col)); /* returnColor[k] += Math.exp(color[k]) */
+         }
+      }
+      return;
+   }
+   case ORC_MAT_CHECKERBOARD:
+      checker_color((const float(*)[3]) o->mm, info->point, &o->ext, out);
+      return;
    default:
       /* ColorInformation.getMaterialColor materials/ColorInformation.java:35-37 */
       memcpy(out, o->mat.diffuse, sizeof(float) * 3);
@@ -681,7 +923,7 @@ static void phong_combine(const float color_in[3], const float kd[3], const floa
 static void pixel_color(ctx *c, const hitinfo *info, float out[3])
 {
    float color[3];
-   material_color(c, info, 0, color);
+   material_color(c, info, 0, 0, color);
    if (c->st->lighting_model == ORC_LIGHTING_PHONG) {
       const object *o = &c->scene->objs[info->obj];
       const v3 light = { c->st->light_origin[0], c->st->light_origin[1], c->st->light_origin[2] };
@@ -881,24 +1123,42 @@ int orc_trace_rays(const orc_scene *s, const orc_settings *st, uint64_t n, const
 
 /* ---------------------------------------------------------------- scene create / camera */
 
-int orc_scene_create(const orc_mesh_desc *meshes, uint32_t n_meshes, const orc_build_opts *opts, orc_scene **out)
+int orc_scene_create_objects(const orc_object_desc *objects, uint32_t n_objects, const orc_build_opts *opts, orc_scene **out)
 {
    orc_scene *s;
    uint32_t i;
-   if (!meshes || !opts || !out) return -1;
+   if ((!objects && n_objects) || !opts || !out) return -1;
    s = (orc_scene *) calloc(1, sizeof(orc_scene));
-   s->objs = (object *) calloc(n_meshes ? n_meshes : 1, sizeof(object));
-   s->n_objs = n_meshes;
-   for (i = 0; i < n_meshes; i++) {
-      const orc_mesh_desc *md = &meshes[i];
+   s->objs = (object *) calloc(n_objects ? n_objects : 1, sizeof(object));
+   s->n_objs = n_objects;
+   for (i = 0; i < n_objects; i++) {
+      const orc_object_desc *od = &objects[i];
+      const orc_mesh_desc *md = &od->mesh;
       object *o = &s->objs[i];
       uint32_t v, f;
       int c;
       int32_t *faces;
       buildctx b;
+      o->kind = od->kind;
+      o->mat = md->material;
+      o->ext = od->ext;
+      if (od->kind == ORC_OBJ_SPHERE) {
+         /* Sphere ctor Sphere.java:15-22, BoundingSphere.getMinMax BoundingSphere.java:105-111 */
+         o->center.x = od->center[0]; o->center.y = od->center[1]; o->center.z = od->center[2];
+         o->radius = od->radius;
+         for (c = 0; c < 3; c++) {
+            o->mm[0][c] = od->center[c] - od->radius;
+            o->mm[1][c] = od->center[c] + od->radius;
+         }
+         continue;
+      }
+      if (od->kind == ORC_OBJ_PLANE) {
+         if (od->n_corners < 3 || od->n_corners > 4 || plane_setup(o, od->corners, od->n_corners) != 0) { orc_scene_destroy(s); return -3; }
+         continue;
+      }
+      if (od->kind != ORC_OBJ_MESH) { orc_scene_destroy(s); return -1; }
       o->n_vertices = md->n_vertices;
       o->n_faces = md->n_faces;
-      o->mat = md->material;
       o->vertices = (float *) malloc(sizeof(float) * 3 * (size_t) (md->n_vertices ? md->n_vertices : 1));
       o->normals = (float *) malloc(sizeof(float) * 3 * (size_t) (md->n_vertices ? md->n_vertices : 1));
       o->indices = (int32_t *) malloc(sizeof(int32_t) * 3 * (size_t) (md->n_faces ? md->n_faces : 1));
@@ -927,6 +1187,22 @@ int orc_scene_create(const orc_mesh_desc *meshes, uint32_t n_meshes, const orc_b
    }
    *out = s;
    return 0;
+}
+
+int orc_scene_create(const orc_mesh_desc *meshes, uint32_t n_meshes, const orc_build_opts *opts, orc_scene **out)
+{
+   orc_object_desc *od;
+   uint32_t i;
+   int rc;
+   if (!meshes || !opts || !out) return -1;
+   od = (orc_object_desc *) calloc(n_meshes ? n_meshes : 1, sizeof(orc_object_desc));
+   for (i = 0; i < n_meshes; i++) {
+      od[i].kind = ORC_OBJ_MESH;
+      od[i].mesh = meshes[i];
+   }
+   rc = orc_scene_create_objects(od, n_meshes, opts, out);
+   free(od);
+   return rc;
 }
 
 void orc_scene_destroy(orc_scene *s)
@@ -1115,6 +1391,42 @@ void orc_reflection_direction(const float n[3], const float dir[3], float out[3]
    v3 N = { n[0], n[1], n[2] }, D = { dir[0], dir[1], dir[2] };
    v3 r = reflection_direction(N, D);
    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+int orc_sphere_intersection(const float o[3], const float d[3], const float center[3], float radius, float eps, int bounding, float out[7])
+{
+   ray r;
+   v3 c = { center[0], center[1], center[2] };
+   r.origin.x = o[0]; r.origin.y = o[1]; r.origin.z = o[2];
+   r.dir.x = d[0]; r.dir.y = d[1]; r.dir.z = d[2];
+   if (bounding) return bounding_sphere_intersects(&r, c, radius, eps);
+   return sphere_intersection(&r, c, radius, eps, out);
+}
+
+int orc_plane_intersection(const float o[3], const float d[3], const float *corners, uint32_t n_corners, float eps, float out[7])
+{
+   object ob;
+   ray r;
+   memset(&ob, 0, sizeof(ob));
+   if (n_corners < 3 || n_corners > 4 || plane_setup(&ob, corners, n_corners) != 0) return -1;
+   r.origin.x = o[0]; r.origin.y = o[1]; r.origin.z = o[2];
+   r.dir.x = d[0]; r.dir.y = d[1]; r.dir.z = d[2];
+   return plane_intersection(&ob, &r, eps, out);
+}
+
+void orc_refraction_direction(const float n[3], const float dir[3], float refraction_index, float out[3])
+{
+   v3 N = { n[0], n[1], n[2] }, D = { dir[0], dir[1], dir[2] };
+   v3 r = refraction_direction(N, D, refraction_index);
+   out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+void orc_checker_color(const float minmax[6], const float point[3], const orc_material_ext *ext, float out[3])
+{
+   float mm[2][3];
+   v3 p = { point[0], point[1], point[2] };
+   memcpy(mm, minmax, sizeof(mm));
+   checker_color((const float(*)[3]) mm, p, ext, out);
 }
 
 void orc_normalize(float v[3])

@@ -23,7 +23,15 @@ extern "C" {
 #endif
 
 /* material kinds: materials/ColorInformation.java, BRDFMaterial.java, ReflectionMaterial.java */
-enum { ORC_MAT_COLOR = 0, ORC_MAT_BRDF = 1, ORC_MAT_REFLECTION = 2 };
+enum { ORC_MAT_COLOR = 0, ORC_MAT_BRDF = 1, ORC_MAT_REFLECTION = 2,
+       ORC_MAT_REFRACTION = 3,    /* materials/RefractionMaterial.java */
+       ORC_MAT_CHECKERBOARD = 4 };/* materials/CheckerboardMaterial.java */
+/* object kinds: bounds/KDTree.java over a TriangleMesh (0), sceneObjects/Sphere.java inside a
+ * bounds/BoundingSphere.java (1), sceneObjects/Plane.java inside a bounds/AxisAlignedBoundingBox.java (2) */
+enum { ORC_OBJ_MESH = 0, ORC_OBJ_SPHERE = 1, ORC_OBJ_PLANE = 2 };
+/* guard (no counterpart in the reference, like max_mirror_bounces): a path carries at most this many pending
+ * RefractionMaterial absorption terms; a further RefractionMaterial hit answers with its diffuse colour */
+#define ORC_MAX_REFRACTION_TERMS 8
 /* lighting models: lighting/LightingModel.java (0), PhongLightingModel.java (1) */
 enum { ORC_LIGHTING_PLAIN = 0, ORC_LIGHTING_PHONG = 1 };
 
@@ -41,6 +49,21 @@ typedef struct {
    uint32_t n_vertices, n_faces;
    orc_material material;
 } orc_mesh_desc;
+
+typedef struct {
+   float refraction_index;                      /* RefractionMaterial.refractionIndex (RefractionMaterial.java:21) */
+   float checker_color1[3], checker_color2[3];  /* CheckerboardMaterial.color1 / color2 */
+   float checker_cell[3];                       /* cellWidth, cellHeight, cellDepth */
+} orc_material_ext;
+
+typedef struct {
+   uint32_t kind;            /* ORC_OBJ_* */
+   orc_mesh_desc mesh;       /* MESH: the arrays; every kind: mesh.material is the object's ColorInformation */
+   orc_material_ext ext;
+   float center[3], radius;  /* SPHERE: Sphere(radius, origin, colorInfo) Sphere.java:15-22 */
+   float corners[12];        /* PLANE: Plane(corners, colorInfo) Plane.java:28-76 */
+   uint32_t n_corners;       /* 3 or 4 */
+} orc_object_desc;
 
 typedef struct {
    int32_t max_depth;     /* RTStatics.MAX_DEPTH    (RTStatics.java:25) */
@@ -78,6 +101,8 @@ typedef struct {
 typedef struct orc_scene orc_scene;
 
 int orc_scene_create(const orc_mesh_desc *meshes, uint32_t n_meshes, const orc_build_opts *opts, orc_scene **out);
+/* any mix of meshes, spheres and planes, in the order of Scene.objects */
+int orc_scene_create_objects(const orc_object_desc *objects, uint32_t n_objects, const orc_build_opts *opts, orc_scene **out);
 void orc_scene_destroy(orc_scene *s);
 int orc_scene_set_brdf(orc_scene *s, const float *angles_nx4, int32_t n_dirs, const float *weights, int32_t n_materials);
 /* object i: 6 floats min xyz, max xyz; shadowDistance; node / leaf / leaf-slot counts, depth */
@@ -104,6 +129,15 @@ int orc_trace_rays(const orc_scene *s, const orc_settings *st, uint64_t n, const
 int orc_aabb_intersection(const float o[3], const float d[3], const float minmax[6], float near_plane, float far_plane);
 int orc_intersects_triangle(const float o[3], const float d[3], const float p[9], const float n[9], float eps, float out[7]);
 void orc_reflection_direction(const float n[3], const float dir[3], float out[3]);
+/* Sphere.getIntersection Sphere.java:29-112 (bounding != 0: BoundingSphere.intersects BoundingSphere.java:29-102, out untouched);
+ * out = point xyz, normal xyz, w; returns 1 on a hit */
+int orc_sphere_intersection(const float o[3], const float d[3], const float center[3], float radius, float eps, int bounding, float out[7]);
+/* Plane ctor + Plane.getIntersection Plane.java:28-154; out as above; returns 1 on a hit, -1 for colinear corners */
+int orc_plane_intersection(const float o[3], const float d[3], const float *corners, uint32_t n_corners, float eps, float out[7]);
+/* RefractionMaterial.getRefractionDirection RefractionMaterial.java:61-95 */
+void orc_refraction_direction(const float n[3], const float dir[3], float refraction_index, float out[3]);
+/* CheckerboardMaterial.getMaterialColor CheckerboardMaterial.java:21-49 */
+void orc_checker_color(const float minmax[6], const float point[3], const orc_material_ext *ext, float out[3]);
 void orc_normalize(float v[3]);
 void orc_image_argb8(const float *rgb, int32_t width, int32_t height, int normalized, uint32_t *out);
 void orc_rgb_to_hsv(const float rgb[3], float hsv[3]);

@@ -7,8 +7,10 @@ torch.distributed (tiles.py).  The directory name is not a Python identifier; im
 `ray_tracer_amd` shim at the repository root.
 """
 from . import _abi, meshgen  # noqa: F401
-from .host import (BRDFMaterial, Camera, ColorInformation, Light, LightingModel, PhongLightingModel,  # noqa: F401
-                   ReflectionMaterial, RTStatics, Scene, TriangleMesh, compute_normals, load_ply)
+from .host import (BRDFMaterial, Camera, CheckerboardMaterial, ColorInformation, Light, LightingModel,  # noqa: F401
+                   PhongLightingModel, Plane, ReflectionMaterial, RefractionMaterial, RTStatics, Scene, Sphere,
+                   TriangleMesh, compute_normals, load_ply)
 
-__all__ = ["BRDFMaterial", "Camera", "ColorInformation", "Light", "LightingModel", "PhongLightingModel",
-           "ReflectionMaterial", "RTStatics", "Scene", "TriangleMesh", "compute_normals", "load_ply", "meshgen"]
+__all__ = ["BRDFMaterial", "Camera", "CheckerboardMaterial", "ColorInformation", "Light", "LightingModel",
+           "PhongLightingModel", "Plane", "ReflectionMaterial", "RefractionMaterial", "RTStatics", "Scene", "Sphere",
+           "TriangleMesh", "compute_normals", "load_ply", "meshgen"]

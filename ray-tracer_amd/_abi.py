@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MI355RT_LIB: tuning builds only (tools/variants.sh); the product is the in-tree libmi355rt.so
 LIB_PATH = os.environ.get("MI355RT_LIB") or os.path.join(_HERE, "libmi355rt.so")
 
-MAT_COLOR, MAT_BRDF, MAT_REFLECTION = 0, 1, 2
+MAT_COLOR, MAT_BRDF, MAT_REFLECTION, MAT_REFRACTION, MAT_CHECKERBOARD = 0, 1, 2, 3, 4
+OBJ_MESH, OBJ_SPHERE, OBJ_PLANE = 0, 1, 2
+MAX_REFRACTION_TERMS = 8
 LIGHTING_PLAIN, LIGHTING_PHONG = 0, 1
 E_ARG, E_DEVICE, E_MEMORY, E_LIMIT, E_IO = -1, -2, -3, -4, -5
 
@@ -29,6 +31,16 @@ class Material(C.Structure):
 class MeshDesc(C.Structure):
     _fields_ = [("vertices", c_float_p), ("normals", c_float_p), ("indices", c_int32_p),
                 ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32), ("material", Material)]
+
+
+class MaterialExt(C.Structure):
+    _fields_ = [("refraction_index", C.c_float), ("checker_color1", C.c_float * 3), ("checker_color2", C.c_float * 3),
+                ("checker_cell", C.c_float * 3)]
+
+
+class ObjectDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("mesh", MeshDesc), ("ext", MaterialExt), ("center", C.c_float * 3),
+                ("radius", C.c_float), ("corners", C.c_float * 12), ("n_corners", C.c_uint32)]
 
 
 class BuildOpts(C.Structure):
@@ -58,8 +70,8 @@ class Stats(C.Structure):
 
 
 COLLECT_COUNTS, COLLECT_TIMES, COLLECT_DIAG = 1, 2, 4
-K_GENERATE, K_WALK_PRIMARY, K_SHADE, K_WALK_SECONDARY, K_WALK_SHADOW, K_PHONG, K_RESOLVE, N_KERNELS = 0, 1, 2, 3, 4, 5, 6, 8
-KERNEL_NAMES = ("generate", "walk_primary", "shade", "walk_secondary", "walk_shadow", "phong", "resolve")
+K_GENERATE, K_WALK_PRIMARY, K_SHADE, K_WALK_SECONDARY, K_WALK_SHADOW, K_PHONG, K_RESOLVE, K_ANALYTIC, N_KERNELS = 0, 1, 2, 3, 4, 5, 6, 7, 8
+KERNEL_NAMES = ("generate", "walk_primary", "shade", "walk_secondary", "walk_shadow", "phong", "resolve", "analytic")
 
 
 class KernelProfile(C.Structure):
@@ -75,6 +87,7 @@ class Frame(C.Structure):
 # name -> (restype, argtypes); exactly the entry points include/mi355rt.h declares
 PROTOTYPES = {
     "mi355rt_scene_create": (C.c_int, [C.POINTER(MeshDesc), C.c_uint32, C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
+    "mi355rt_scene_create_objects": (C.c_int, [C.POINTER(ObjectDesc), C.c_uint32, C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
     "mi355rt_scene_destroy": (None, [C.c_void_p]),
     "mi355rt_brdf_tables": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_float_p, C.c_int32]),
     "mi355rt_scene_epsilon": (C.c_int, [C.c_void_p, c_float_p]),

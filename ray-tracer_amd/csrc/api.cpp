@@ -67,6 +67,7 @@ struct HostObject {
    float shadow_distance;
    uint64_t n_nodes, n_leaves, n_slots;
    int32_t max_depth;
+   bool is_mesh;
 };
 
 }   // namespace
@@ -74,7 +75,8 @@ struct HostObject {
 // device scratch of one frame pass (layout.h "FRAME SCRATCH")
 struct FrameScratch {
    size_t cap = 0;        // sample slots
-   bool with_mirror = false;
+   bool with_mirror = false, with_refraction = false;
+   float *refr_parent = nullptr, *refr_terms = nullptr;
    float *samples = nullptr, *rays0 = nullptr, *hits0 = nullptr, *mat0 = nullptr;
    int32_t *hit_obj0 = nullptr;
    uint32_t *shadow = nullptr;
@@ -90,6 +92,9 @@ struct mi355rt_scene {
    std::vector<HostObject> objects;
    std::vector<mi355rt_material> materials;
    DevObject *d_objs = nullptr;
+   DevObjectExt *d_ext = nullptr;   // parallel to d_objs: sphere / plane / refraction / checkerboard parameters
+   int n_analytic = 0;              // spheres + planes
+   bool has_refraction = false;
    void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;   // all objects, concatenated
    float *d_brdf_dirs = nullptr, *d_brdf_weights = nullptr;
    int32_t n_dirs = 0, n_materials = 0;
@@ -123,7 +128,8 @@ namespace {
 
 void free_scratch(FrameScratch &fs)
 {
-   void *all[] = { fs.samples, fs.rays0, fs.hits0, fs.mat0, fs.hit_obj0, fs.shadow, fs.rays1[0], fs.rays1[1], fs.hits1, fs.hit_obj1 };
+   void *all[] = { fs.samples, fs.rays0, fs.hits0, fs.mat0, fs.hit_obj0, fs.shadow, fs.rays1[0], fs.rays1[1], fs.hits1, fs.hit_obj1,
+                   fs.refr_parent, fs.refr_terms };
    for (void *q : all)
       if (q) (void) hipFree(q);
    fs = FrameScratch();
@@ -136,6 +142,7 @@ void release_scene(mi355rt_scene *s)
    if (s->d_tris) (void) hipFree(s->d_tris);
    if (s->d_fnrm) (void) hipFree(s->d_fnrm);
    if (s->d_objs) (void) hipFree(s->d_objs);
+   if (s->d_ext) (void) hipFree(s->d_ext);
    if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
    if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
    if (s->d_counters) (void) hipFree(s->d_counters);
@@ -223,17 +230,74 @@ int check_settings(const mi355rt_settings *st)
    if (st->lighting_model != MI355RT_LIGHTING_PLAIN && st->lighting_model != MI355RT_LIGHTING_PHONG)
       return fail(MI355RT_E_ARG, "unknown lighting_model");
    if (st->max_mirror_bounces < 0) return fail(MI355RT_E_ARG, "max_mirror_bounces must be >= 0");
+   if (st->max_mirror_bounces > 2047) return fail(MI355RT_E_LIMIT, "max_mirror_bounces must be <= 2047");
    return MI355RT_OK;
 }
 
+void set_material(DevObject &d, const mi355rt_material &m)
+{
+   d.mat.kind = m.kind;
+   std::memcpy(d.mat.diffuse, m.diffuse, sizeof(d.mat.diffuse));
+   std::memcpy(d.mat.specular, m.specular, sizeof(d.mat.specular));
+   d.mat.shininess = m.shininess;
+   d.mat.brdf_id = m.brdf_id;
+}
+
+// Sphere ctor (sceneObjects/Sphere.java:15-22) with BoundingSphere.getMinMax (bounds/BoundingSphere.java:105-111), or the
+// Plane ctor (sceneObjects/Plane.java:28-76).  Returns an error text, empty on success.
+std::string add_analytic_object(mi355rt_scene *s, const mi355rt_object_desc &od, DevObject &d, DevObjectExt &ext)
+{
+   HostObject ho;
+   std::memset(&ho, 0, sizeof(ho));
+   ho.is_mesh = false;
+   if (od.kind == MI355RT_OBJ_SPHERE) {
+      for (int c = 0; c < 3; c++) {
+         ext.center[c] = od.center[c];
+         ho.bmin[c] = od.center[c] - od.radius;
+         ho.bmax[c] = od.center[c] + od.radius;
+      }
+      ext.radius = od.radius;
+      d.kind = OBJ_SPHERE;
+   } else {
+      float c[4][3];
+      for (int i = 0; i < 4; i++)
+         for (int k = 0; k < 3; k++) c[i][k] = od.corners[3 * ((uint32_t) i < od.n_corners ? i : 2) + k];   // :60-63 a triangle repeats its third corner
+      ext.pA = c[0][1] * (c[1][2] - c[2][2]) + c[1][1] * (c[2][2] - c[0][2]) + c[2][1] * (c[0][2] - c[1][2]);
+      ext.pB = c[0][2] * (c[1][0] - c[2][0]) + c[1][2] * (c[2][0] - c[0][0]) + c[2][2] * (c[0][0] - c[1][0]);
+      ext.pC = c[0][0] * (c[1][1] - c[2][1]) + c[1][0] * (c[2][1] - c[0][1]) + c[2][0] * (c[0][1] - c[1][1]);
+      ext.pD = -(c[0][0] * (c[1][1] * c[2][2] - c[2][1] * c[1][2]) + c[1][0] * (c[2][1] * c[0][2] - c[0][1] * c[2][2]) +
+                 c[2][0] * (c[0][1] * c[1][2] - c[1][1] * c[0][2]));
+      if ((ext.pA == 0) && (ext.pB == 0) && (ext.pC == 0)) return "the first three corners of the plane are colinear (Plane.java:56-58)";
+      const float len2 = ext.pA * ext.pA + ext.pB * ext.pB + ext.pC * ext.pC;
+      const float rn = (float) (1.0 / std::sqrt((double) len2));   // Vector3f.normalize
+      ext.pnormal[0] = ext.pA * rn;
+      ext.pnormal[1] = ext.pB * rn;
+      ext.pnormal[2] = ext.pC * rn;
+      for (int k = 0; k < 3; k++) {
+         ho.bmin[k] = jm::fmin_java(c[0][k], jm::fmin_java(c[1][k], jm::fmin_java(c[2][k], c[3][k])));
+         ho.bmax[k] = jm::fmax_java(c[0][k], jm::fmax_java(c[1][k], jm::fmax_java(c[2][k], c[3][k])));
+      }
+      d.kind = OBJ_PLANE;
+   }
+   std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
+   std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
+   d.root_entry = STACK_EMPTY;   // the walker passes over it
+   set_material(d, od.mesh.material);
+   s->objects.push_back(ho);
+   s->materials.push_back(od.mesh.material);
+   s->n_analytic++;
+   if (s->max_normal_len < 1.0001f) s->max_normal_len = 1.0001f;   // analytic normals are unit length (a NaN from a mesh stays)
+   return std::string();
+}
+
 // a pass renders at most this many sample slots at once (bounds the scratch: ~104 B per slot,
-// ~204 B with mirrors)
+// ~204 B with mirrors, 144 B more with a RefractionMaterial)
 constexpr size_t PASS_SLOTS = (size_t) 1 << 24;
 
-int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror)
+int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_refraction)
 {
    FrameScratch &fs = s->scratch;
-   if (fs.cap >= cap && (fs.with_mirror || !with_mirror)) return MI355RT_OK;
+   if (fs.cap >= cap && (fs.with_mirror || !with_mirror) && (fs.with_refraction || !with_refraction)) return MI355RT_OK;
    free_scratch(fs);
    struct Want {
       void **dst;
@@ -244,6 +308,8 @@ int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror)
       { (void **) &fs.mat0, cap * 16 },     { (void **) &fs.hit_obj0, cap * 4 },  { (void **) &fs.shadow, cap * 4 },
       { (void **) &fs.rays1[0], with_mirror ? cap * 32 : 0 }, { (void **) &fs.rays1[1], with_mirror ? cap * 32 : 0 },
       { (void **) &fs.hits1, with_mirror ? cap * 32 : 0 },    { (void **) &fs.hit_obj1, with_mirror ? cap * 4 : 0 },
+      { (void **) &fs.refr_parent, with_refraction ? cap * 16 : 0 },
+      { (void **) &fs.refr_terms, with_refraction ? cap * 16 * MAX_REFRACTION_TERMS : 0 },
    };
    for (const Want &w : wants) {
       if (!w.bytes) continue;
@@ -256,6 +322,7 @@ int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror)
    }
    fs.cap = cap;
    fs.with_mirror = with_mirror;
+   fs.with_refraction = with_refraction;
    return MI355RT_OK;
 }
 
@@ -280,8 +347,8 @@ bool shadow_any_hit_is_exact(const mi355rt_scene *s, const mi355rt_settings *st)
       dl2 += d * d;
    }
    if (!(st->epsilon >= 0.0f) || !std::isfinite(s->max_normal_len)) return false;
-   for (const HostObject &o : s->objects)
-      if (!(o.shadow_distance >= st->epsilon)) return false;
+   for (const HostObject &o : s->objects)   // mesh candidates only: spheres and planes are tested in full by analytic_shadow_kernel
+      if (o.is_mesh && !(o.shadow_distance >= st->epsilon)) return false;
    const double reach = std::sqrt(diag2) + 2.0 * (double) s->max_normal_len * (double) st->epsilon + (double) st->epsilon;
    return std::sqrt(dl2) > 1.01 * reach + 1e-6 * (double) s->abs_max;
 }
@@ -303,6 +370,9 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.sc.near_plane = st->near_plane;
    p.sc.far_plane = st->far_plane;
    p.sc.scene_abs_max = s->abs_max;
+   p.sc.ext = s->d_ext;
+   p.sc.n_analytic = s->n_analytic;
+   p.max_recursion_depth = st->max_recursion_depth;
    std::memcpy(p.origin, cam->origin, sizeof(p.origin));
    std::memcpy(p.rot, cam->rotation, sizeof(p.rot));
    // Camera.createImage constants (Camera.java:123-126)
@@ -329,7 +399,7 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    for (size_t i = 0; i < s->materials.size(); i++) {
       const mi355rt_material &m = s->materials[i];
       if (m.kind == MI355RT_MAT_BRDF && (m.brdf_id < 0 || m.brdf_id >= s->n_materials))
-         return fail(MI355RT_E_ARG, "mesh " + std::to_string(i) + ": BRDF material row " + std::to_string(m.brdf_id) +
+         return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": BRDF material row " + std::to_string(m.brdf_id) +
                                         " is outside the loaded tables (call mi355rt_brdf_tables first)");
    }
    int tile = st->tile_size == 0 ? 16 : st->tile_size;
@@ -361,7 +431,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
    const size_t slots_per_micro = (size_t) 64 * (size_t) p.multi_samples;
    const long long micro_per_pass = (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
    const long long first_pass = std::min(n_micro, micro_per_pass);
-   if (int rc = ensure_scratch(s, (size_t) ((first_pass + N_BANDS - 1) / N_BANDS) * N_BANDS * slots_per_micro, s->has_mirror)) return rc;
+   if (int rc = ensure_scratch(s, (size_t) ((first_pass + N_BANDS - 1) / N_BANDS) * N_BANDS * slots_per_micro, s->has_mirror || s->has_refraction, s->has_refraction)) return rc;
    const FrameScratch &fs = s->scratch;
    p.samples = fs.samples;
    p.rays0 = fs.rays0;
@@ -373,6 +443,8 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
    p.rays1[1] = fs.rays1[1];
    p.hits1 = fs.hits1;
    p.hit_obj1 = fs.hit_obj1;
+   p.refr_parent = fs.refr_parent;
+   p.refr_terms = fs.refr_terms;
    p.counters = s->d_counters;
    if (p.stats) {
       s->stats_accum = mi355rt_stats {};
@@ -393,9 +465,12 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       HIP_TRY(timer.run(MI355RT_K_WALK_PRIMARY, [&] {
          return launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cw0, p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, p.diag, stream);
       }));
+      if (s->n_analytic) HIP_TRY(timer.run(MI355RT_K_ANALYTIC, [&] {
+         return launch_analytic_closest(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, p.band_cap, slots, s->n_cus, p.stats, stream);
+      }));
       HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream); }));
-      if (s->has_mirror) {
-         // mirror bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
+      if (s->has_mirror || s->has_refraction) {
+         // mirror / refraction bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
          int cur = 0;
          for (int bounce = 0; bounce <= p.max_mirror_bounces; bounce++) {
             uint32_t n_band[N_BANDS];
@@ -412,6 +487,9 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
             HIP_TRY(timer.run(MI355RT_K_WALK_SECONDARY, [&] {
                return launch_trace(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, cw, p.band_cap, n_sec, s->n_cus, p.stats ? 1 : 0, p.diag, stream);
             }));
+            if (s->n_analytic) HIP_TRY(timer.run(MI355RT_K_ANALYTIC, [&] {
+               return launch_analytic_closest(p.sc, p.rays1[cur], p.hits1, p.hit_obj1, p.counters, cur_cnt, p.band_cap, n_sec, s->n_cus, 0, stream);
+            }));
             HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 1, p.rays1[cur], p.hits1, p.hit_obj1, cur_cnt, p.rays1[cur ^ 1], nxt_cnt, n_sec, s->n_cus, stream); }));
             cur ^= 1;
          }
@@ -419,6 +497,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       if (p.lighting_model == MI355RT_LIGHTING_PHONG) {
          const int cw = CNT_CURSOR0 + 8 * (CNT_CURSOR_SETS - 1);
          HIP_TRY(timer.run(MI355RT_K_WALK_SHADOW, [&] { return launch_shadow(p, cw, slots, s->n_cus, stream); }));
+         if (s->n_analytic) HIP_TRY(timer.run(MI355RT_K_ANALYTIC, [&] { return launch_analytic_shadow(p, slots, s->n_cus, stream); }));
          HIP_TRY(timer.run(MI355RT_K_PHONG, [&] { return launch_phong(p, slots, s->n_cus, stream); }));
       }
       HIP_TRY(timer.run(MI355RT_K_RESOLVE, [&] { return launch_resolve(p, stream); }));
@@ -452,15 +531,19 @@ int mi355rt_device_count(void)
    return n;
 }
 
-int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts, mi355rt_scene **out)
+int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_meshes, const mi355rt_build_opts *opts, mi355rt_scene **out)
 {
    if (!out) return fail(MI355RT_E_ARG, "out is null");
    *out = nullptr;
    if (!opts) return fail(MI355RT_E_ARG, "build options are null");
-   if (n_meshes && !meshes) return fail(MI355RT_E_ARG, "meshes is null");
-   if (n_meshes > (uint32_t) MAX_OBJECTS) return fail(MI355RT_E_LIMIT, "more than " + std::to_string(MAX_OBJECTS) + " meshes");
+   if (n_meshes && !objects) return fail(MI355RT_E_ARG, "objects is null");
+   if (n_meshes > (uint32_t) MAX_OBJECTS) return fail(MI355RT_E_LIMIT, "more than " + std::to_string(MAX_OBJECTS) + " objects");
    for (uint32_t i = 0; i < n_meshes; i++) {
-      if (meshes[i].material.kind > MI355RT_MAT_REFLECTION) return fail(MI355RT_E_ARG, "unknown material kind on mesh " + std::to_string(i));
+      const mi355rt_object_desc &od = objects[i];
+      if (od.kind > MI355RT_OBJ_PLANE) return fail(MI355RT_E_ARG, "unknown kind of object " + std::to_string(i));
+      if (od.mesh.material.kind > MI355RT_MAT_CHECKERBOARD) return fail(MI355RT_E_ARG, "unknown material kind on object " + std::to_string(i));
+      if (od.kind == MI355RT_OBJ_PLANE && (od.n_corners < 3 || od.n_corners > 4))
+         return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": a plane takes 3 or 4 corners");
    }
    int n_dev = 0;
    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
@@ -486,6 +569,8 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
    }
    std::vector<DevObject> dev_objs(n_meshes ? n_meshes : 1);
    std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
+   std::vector<DevObjectExt> dev_ext(dev_objs.size());
+   std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
    // all objects share one node array, one slot array and one normal array (links absolute)
    std::vector<NodeRec> all_nodes;
    std::vector<float> all_tris, all_fnrm;
@@ -493,7 +578,23 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
 
    try {
       for (uint32_t i = 0; i < n_meshes; i++) {
-         const mi355rt_mesh_desc &md = meshes[i];
+         const mi355rt_object_desc &od = objects[i];
+         const mi355rt_mesh_desc &md = od.mesh;
+         DevObjectExt &ext = dev_ext[i];
+         ext.refraction_index = od.ext.refraction_index;
+         std::memcpy(ext.color1, od.ext.checker_color1, sizeof(ext.color1));
+         std::memcpy(ext.color2, od.ext.checker_color2, sizeof(ext.color2));
+         std::memcpy(ext.cell, od.ext.checker_cell, sizeof(ext.cell));
+         if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
+         if (md.material.kind == MI355RT_MAT_REFRACTION) s->has_refraction = true;
+         if (od.kind != MI355RT_OBJ_MESH) {
+            const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
+            if (!err.empty()) {
+               release_scene(s);
+               return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": " + err);
+            }
+            continue;
+         }
          BuiltObject bo_out;
          const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo, bo_out);
          if (!err.empty()) {
@@ -542,7 +643,6 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
 
          s->objects.emplace_back();
          s->materials.push_back(md.material);
-         if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
          for (size_t v = 0; v + 2 < bo_out.normals.size(); v += 3) {
             const float *nv = bo_out.normals.data() + v;
             const float len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
@@ -556,7 +656,9 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
          ho.n_leaves = bo_out.n_leaves;
          ho.n_slots = bo_out.slot_face.size();
          ho.max_depth = bo_out.max_depth;
+         ho.is_mesh = true;
          DevObject &d = dev_objs[i];
+         d.kind = OBJ_MESH;
          std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
          std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
          d.root_entry = !bo_out.root_is_leaf ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
@@ -564,11 +666,9 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
          d.face_base = (int32_t) face_base;
          d.node_base = (int32_t) node_base;
          d.slot_base = (int32_t) slot_base;
-         d.mat.kind = md.material.kind;
-         std::memcpy(d.mat.diffuse, md.material.diffuse, sizeof(d.mat.diffuse));
-         std::memcpy(d.mat.specular, md.material.specular, sizeof(d.mat.specular));
-         d.mat.shininess = md.material.shininess;
-         d.mat.brdf_id = md.material.brdf_id;
+         set_material(d, md.material);
+      }
+      for (const HostObject &ho : s->objects) {   // Scene.java:21-33
          for (int c = 0; c < 3; c++) {
             s->smin[c] = jm::fmin_java(s->smin[c], ho.bmin[c]);
             s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
@@ -598,7 +698,8 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
    }
    s->abs_max = n_meshes ? amax : 0.f;
    int rc;
-   if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s))) {
+   if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s)) ||
+       (rc = upload(dev_ext.data(), sizeof(DevObjectExt) * dev_ext.size(), (void **) &s->d_ext, s))) {
       release_scene(s);
       return rc;
    }
@@ -611,6 +712,23 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
    *out = s;
    return MI355RT_OK;
+}
+
+int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts, mi355rt_scene **out)
+{
+   if (!out) return fail(MI355RT_E_ARG, "out is null");
+   *out = nullptr;
+   if (n_meshes && !meshes) return fail(MI355RT_E_ARG, "meshes is null");
+   for (uint32_t i = 0; i < n_meshes; i++) {
+      if (meshes[i].material.kind > MI355RT_MAT_REFLECTION) return fail(MI355RT_E_ARG, "unknown material kind on mesh " + std::to_string(i));
+   }
+   std::vector<mi355rt_object_desc> objects(n_meshes ? n_meshes : 1);
+   std::memset(objects.data(), 0, sizeof(mi355rt_object_desc) * objects.size());
+   for (uint32_t i = 0; i < n_meshes; i++) {
+      objects[i].kind = MI355RT_OBJ_MESH;
+      objects[i].mesh = meshes[i];
+   }
+   return mi355rt_scene_create_objects(objects.data(), n_meshes, opts, out);
 }
 
 void mi355rt_scene_destroy(mi355rt_scene *scene)
@@ -892,6 +1010,8 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    a.sc.near_plane = settings->near_plane;
    a.sc.far_plane = settings->far_plane;
    a.sc.scene_abs_max = scene->abs_max;
+   a.sc.ext = scene->d_ext;
+   a.sc.n_analytic = scene->n_analytic;
    a.n = (uint32_t) n;
    a.band_cap = (uint32_t) ((n + N_BANDS - 1) / N_BANDS);
    a.origins = (const float *) buf.p[0];
@@ -908,6 +1028,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    HIP_TRY(hipMemsetAsync(scene->d_counters, 0, CNT_WORDS * sizeof(uint32_t), nullptr));
    HIP_TRY(launch_batch_pack(a, nullptr));
    HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, a.band_cap, n, scene->n_cus, 0, 0, nullptr));
+   HIP_TRY(launch_analytic_closest(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, a.band_cap, n, scene->n_cus, 0, nullptr));
    HIP_TRY(launch_batch_unpack(a, nullptr));
    HIP_TRY(hipStreamSynchronize(nullptr));
    if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[5], sizes[5], hipMemcpyDeviceToHost));

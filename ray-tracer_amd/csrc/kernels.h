@@ -13,6 +13,10 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
 hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const float *hits, const int32_t *hit_obj, int count_index,
                         float *rays_next, int next_count_index, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long long max_items, int n_cus, hipStream_t stream);
+// spheres and planes (analytic_kernels.hip): fold their hits into the records the walker left; no-ops for mesh-only scenes
+hipError_t launch_analytic_closest(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
+                                   unsigned band_cap, unsigned long long max_items, int n_cus, int count_hits, hipStream_t stream);
+hipError_t launch_analytic_shadow(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_resolve(const FrameArgs &p, hipStream_t stream);
 hipError_t launch_image(const float *rgb, unsigned long long n_pixels, int normalized, unsigned *minmax2, unsigned *argb, int n_cus, hipStream_t stream);

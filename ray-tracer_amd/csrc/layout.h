@@ -30,6 +30,7 @@
 //   hits    : 2 x float4 per queued ray { P.xyz, w } { N.xyz, bits(face) }, plus hit_obj int (-1 miss)
 //   mat     : float4 per PRIMARY queue entry { material colour rgb, bits(occluded) }
 //   shadow  : u32 per shadow ray = index of its primary queue entry
+//   refr_*  : RefractionMaterial bookkeeping per primary queue entry (see FrameArgs)
 //   counters: queue sizes and the work cursors of the persistent trace launches
 #pragma once
 #include <stdint.h>
@@ -58,14 +59,32 @@ struct DevMaterial {
    int32_t brdf_id;
 };
 
+// Spheres and planes are entries of the same object array with an empty hierarchy
+// (root_entry == STACK_EMPTY, so the walker passes over them); their parameters and the parameters of the
+// refraction / checkerboard materials sit in a parallel DevObjectExt array read by analytic_kernels.hip and
+// the shade kernel only.
+enum { OBJ_MESH = 0, OBJ_SPHERE = 1, OBJ_PLANE = 2 };
+enum { MAT_COLOR = 0, MAT_BRDF = 1, MAT_REFLECTION = 2, MAT_REFRACTION = 3, MAT_CHECKERBOARD = 4 };
+constexpr int MAX_REFRACTION_TERMS = 8;   // MI355RT_MAX_REFRACTION_TERMS
+
+struct DevObjectExt {
+   float center[3], radius;      // Sphere.origin, Sphere.radius
+   float pA, pB, pC, pD;         // Plane.A .. Plane.D
+   float pnormal[3];             // Plane.normal
+   float refraction_index;       // RefractionMaterial.refractionIndex
+   float color1[3], color2[3];   // CheckerboardMaterial.color1 / color2
+   float cell[3];                // cellWidth, cellHeight, cellDepth
+};
+
 struct DevObject {
-   float bmin[3], bmax[3];     // KDTree.minMax
+   float bmin[3], bmax[3];     // KDTree.minMax / BoundingSphere.getMinMax / the Plane's AxisAlignedBoundingBox
    int32_t root_entry;         // node index, ~first_slot when the root is a leaf, STACK_EMPTY for an empty mesh
    float shadow_distance;      // KDTree.shadowDistance
    int32_t face_base;          // first row of this object's faces in fnrm
    int32_t node_base, slot_base;
    DevMaterial mat;
-   int32_t pad_[2];
+   int32_t kind;               // OBJ_*
+   int32_t pad_;
 };
 
 // what every kernel needs to walk the scene.  All objects share one node array and one slot array:
@@ -78,6 +97,8 @@ struct SceneArgs {
    int32_t n_objs;
    float epsilon, near_plane, far_plane;
    float scene_abs_max;   // max |coordinate| of the scene bounds (prune margin)
+   const DevObjectExt *ext;   // [n_objs]
+   int32_t n_analytic;        // spheres + planes among the objects
 };
 
 // Every queue is N_BANDS sub-queues of band_cap slots each: the pass's 8x8 pixel groups are cut into
@@ -109,6 +130,7 @@ struct FrameArgs {
    int32_t width, height;
    // settings
    int32_t multi_samples, brdf_samples, lighting_model, max_mirror_bounces;
+   int32_t max_recursion_depth;   // SceneObject.getColor's cut-off (spheres and planes only)
    uint64_t rng_seed;
    float light_origin[3], light_emission[3], light_ambient[3];
    int32_t shadow_any_hit;   // host-proven: any accepted hit occludes (see api.cpp)
@@ -129,6 +151,10 @@ struct FrameArgs {
    float *rays1[2];     // secondary queues (null when the scene has no mirror)
    float *hits1;        // 2 x float4[cap]
    int32_t *hit_obj1;
+   // RefractionMaterial (null when the scene has none): per path the hit point of the refracting surface whose
+   // absorption term is pending, and the stack of terms gathered so far (applied deepest first at the path's end)
+   float *refr_parent;  // float4[cap] { P.xyz, - }
+   float *refr_terms;   // float4[cap * MAX_REFRACTION_TERMS] { exponent rgb, - }
    uint32_t *counters;  // CNT_WORDS
    // outputs
    float *rgb;

@@ -28,214 +28,14 @@
 
 #include <cstdlib>
 
+#include "analytic.h"
+#include "device_util.h"
 #include "kernels.h"
 #include "layout.h"
 
 namespace mi355rt {
 
 namespace {
-
-struct V3 {
-   float x, y, z;
-};
-
-__device__ __forceinline__ V3 mk3(float x, float y, float z)
-{
-   V3 r;
-   r.x = x;
-   r.y = y;
-   r.z = z;
-   return r;
-}
-__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 add3(V3 a, V3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 scale3(V3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
-// Vector3f.dot: (x*x' + y*y') + z*z'
-__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-// Vector3f.cross(a, b)
-__device__ __forceinline__ V3 cross3(V3 a, V3 b) { return mk3(a.y * b.z - a.z * b.y, b.x * a.z - b.z * a.x, a.x * b.y - a.y * b.x); }
-// Vector3f.normalize
-__device__ __forceinline__ V3 normalize3(V3 a)
-{
-   const float s = a.x * a.x + a.y * a.y + a.z * a.z;
-   const float n = (float) (1.0 / sqrt((double) s));
-   return mk3(a.x * n, a.y * n, a.z * n);
-}
-// RTStatics.getDistance: (float) Math.sqrt((double) f32 sum of squares); for an f32 argument the
-// correctly rounded f32 sqrt is the same value.
-__device__ __forceinline__ float distance3(V3 a, V3 b)
-{
-   const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-   return __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-}
-// RTStatics.getReflectionDirection(n, dir)
-__device__ __forceinline__ V3 reflect3(V3 n, V3 dir)
-{
-   V3 N = scale3(n, 2.0f);
-   N = scale3(N, dot3(dir, n));
-   return normalize3(sub3(dir, N));
-}
-
-struct Ray {
-   V3 o, d, inv;
-};
-
-__device__ __forceinline__ void make_ray(Ray &r, V3 o, V3 d)
-{
-   r.o = o;
-   r.d = d;
-   r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-}
-
-// RTStatics.aabbIntersection (RTStatics.java:102-158) with 1/direction hoisted out (same value on
-// every call for one ray).  Branch-free: after a "return false" nothing else is observable, so
-// evaluating the rest is equivalent.  Every comparison is the reference's own, so NaNs fall
-// through exactly as they do there.
-__device__ __forceinline__ bool slab_test(const Ray &r, float nearp, float farp, float lox, float loy, float loz, float hix,
-                                          float hiy, float hiz, float &t_enter)
-{
-   float txmin, txmax, tymin, tymax, tzmin, tzmax;
-   if (r.inv.x >= 0) {
-      txmin = (lox - r.o.x) * r.inv.x;
-      txmax = (hix - r.o.x) * r.inv.x;
-   } else {
-      txmin = (hix - r.o.x) * r.inv.x;
-      txmax = (lox - r.o.x) * r.inv.x;
-   }
-   if (r.inv.y >= 0) {
-      tymin = (loy - r.o.y) * r.inv.y;
-      tymax = (hiy - r.o.y) * r.inv.y;
-   } else {
-      tymin = (hiy - r.o.y) * r.inv.y;
-      tymax = (loy - r.o.y) * r.inv.y;
-   }
-   bool ok = !(txmin > tymax || tymin > txmax);
-   if (tymin > txmin) txmin = tymin;
-   if (tymax < txmax) txmax = tymax;
-   if (r.inv.z >= 0) {
-      tzmin = (loz - r.o.z) * r.inv.z;
-      tzmax = (hiz - r.o.z) * r.inv.z;
-   } else {
-      tzmin = (hiz - r.o.z) * r.inv.z;
-      tzmax = (loz - r.o.z) * r.inv.z;
-   }
-   ok = ok && !(txmin > tzmax || tzmin > txmax);
-   if (tzmin > txmin) txmin = tzmin;
-   if (tzmax < txmax) txmax = tzmax;
-   t_enter = txmin;
-   return ok && (txmin < farp) && (txmax > nearp);
-}
-
-// Squared distance from the ray origin to a box; NaN terms are ignored (=> smaller => less pruning).
-__device__ __forceinline__ float origin_box_dist2(const Ray &r, float lox, float loy, float loz, float hix, float hiy, float hiz)
-{
-   const float dx = fmaxf(fmaxf(lox - r.o.x, r.o.x - hix), 0.0f);
-   const float dy = fmaxf(fmaxf(loy - r.o.y, r.o.y - hiy), 0.0f);
-   const float dz = fmaxf(fmaxf(loz - r.o.z, r.o.z - hiz), 0.0f);
-   return dx * dx + dy * dy + dz * dz;
-}
-
-__device__ __forceinline__ float prune_limit2(const Ray &r, float w, float scene_abs_max)
-{
-   const float lim = w * 1.0001f + 1e-5f * (scene_abs_max + fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
-   return lim * lim;
-}
-
-// Triangle.intersectsTriangle (sceneObjects/Triangle.java:85-133) on one leaf slot.
-// Returns false where the reference returns null; otherwise the barycentrics, the interpolated
-// point and its distance from the origin (returnValue[6]).
-__device__ __forceinline__ bool tri_test(const float4 A, const float4 B, const float4 C, const Ray &r, float eps, float &u, float &v,
-                                         V3 &P, float &dist)
-{
-   const V3 p0 = mk3(A.x, A.y, A.z);
-   const V3 e1 = sub3(mk3(B.x, B.y, B.z), p0);
-   const V3 e2 = sub3(mk3(C.x, C.y, C.z), p0);
-   const V3 p = cross3(r.d, e2);
-   const float divisor = dot3(p, e1);
-   if ((divisor < eps) && (divisor > -eps)) return false;
-   const V3 T = sub3(r.o, p0);
-   const V3 q = cross3(T, e1);
-   u = dot3(p, T) / divisor;
-   if ((u < 0) || (u > 1)) return false;
-   v = dot3(q, r.d) / divisor;
-   if ((v < 0) || (v + u > 1)) return false;
-   const float wb = 1.0f - u - v;
-   P = mk3(wb * A.x + u * B.x + v * C.x, wb * A.y + u * B.y + v * C.y, wb * A.z + u * B.z + v * C.z);
-   dist = distance3(r.o, P);
-   return true;
-}
-
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
-{
-   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-   return v;
-}
-
-__device__ __forceinline__ void add_stat(uint32_t *counters, int which, unsigned v)
-{
-   const unsigned long long s = wave_sum((unsigned long long) v);
-   if ((threadIdx.x & 63) == 0 && s) atomicAdd((unsigned long long *) (counters + CNT_STATS) + which, s);
-}
-enum { ST_PRIMARY = 0, ST_SHADOW = 1, ST_SECONDARY = 2, ST_BOX = 3, ST_TRI = 4, ST_HITS = 5,
-       // walker diagnostics (collect_stats builds only): lane-trips and wave-trips of each phase
-       ST_NODE_LANE = 6, ST_NODE_WAVE = 7, ST_LEAF_LANE = 8, ST_LEAF_WAVE = 9, ST_OUTER_WAVE = 10, ST_REFILL = 11,
-       // per walker launch kind (0 primary, 1 secondary, 2 shadow): rays, box tests, triangle tests
-       ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22,
-       // per kind, 6 slots each: ~min t_begin, ~min t_queue_dry, max t_queue_dry, max t_end (100 MHz ticks), most trips of one ray, waves that got a ray
-       ST_KIND_TIMELINE = 25,
-       // rays of the LAST walker launch by trips taken: < 16, 32, 64, 128, 256, 512, 1024, more (8 slots per kind: primary 43.., shadow 51..)
-       ST_TRIP_HIST = 43,
-       ST_TAIL_TRIPS = 59 };   // {max, sum} of wave trips after the queue ran dry: primary 59,60; shadow 61,62
-
-// number of set bits of mask below this lane
-__device__ __forceinline__ int rank_below(unsigned long long mask)
-{
-   return (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, 0u));
-}
-
-// true on exactly one of the currently active lanes
-__device__ __forceinline__ bool first_active_lane()
-{
-   const unsigned long long m = __ballot(1);
-   return (int) (threadIdx.x & 63) == (__ffsll((unsigned long long) m) - 1);
-}
-
-// appends one record per lane with `push` set; returns the lane's index (wave-aggregated atomic)
-__device__ __forceinline__ unsigned queue_push(unsigned *count, bool push)
-{
-   const unsigned long long mask = __ballot(push);
-   if (mask == 0ull) return 0u;
-   const int lane = threadIdx.x & 63;
-   const int leader = __ffsll((unsigned long long) mask) - 1;
-   unsigned base = 0;
-   if (lane == leader) base = atomicAdd(count, (unsigned) __popcll(mask));
-   base = (unsigned) __shfl((int) base, leader, 64);
-   return base + (unsigned) __popcll(mask & ((1ull << lane) - 1ull));
-}
-
-// The same for a whole workgroup whose waves all append to ONE queue: one atomic per workgroup.  (An atomic
-// that returns a value costs a round trip to the memory side, and the queue counters are only eight words: with
-// one atomic per wave generate_kernel spent 0.6 of its 0.73 ms waiting for them.)  Every thread of the workgroup
-// must call it; s_cnt holds WAVES + 1 words.
-template <int WAVES> __device__ __forceinline__ unsigned block_queue_push(unsigned *count, bool push, unsigned *s_cnt)
-{
-   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-   const unsigned long long mask = __ballot(push);
-   if (lane == 0) s_cnt[w] = (unsigned) __popcll(mask);
-   __syncthreads();
-   unsigned before = 0, total = 0;
-#pragma unroll
-   for (int i = 0; i < WAVES; i++) {
-      const unsigned c = s_cnt[i];
-      before += i < w ? c : 0u;
-      total += c;
-   }
-   if (threadIdx.x == 0) s_cnt[WAVES] = total ? atomicAdd(count, total) : 0u;
-   __syncthreads();
-   const unsigned base = s_cnt[WAVES];
-   __syncthreads();   // s_cnt may be reused by the next call
-   return base + before + (unsigned) __popcll(mask & ((1ull << lane) - 1ull));
-}
 
 // ---------------------------------------------------------------- colour / BRDF (device)
 
@@ -508,6 +308,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
       any_root = any_root || slab_test(r, p.sc.near_plane, p.sc.far_plane, ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0],
                                        ob.bmax[1], ob.bmax[2], te);
    }
+   if (p.sc.n_analytic > 0) any_root = true;   // spheres have their own bounding test (BoundingSphere.java:29-102): analytic_kernels.hip
    const bool push = active && any_root;
    if (active && !any_root) {
       ((float4 *) p.samples)[slot] = make_float4(p.light_ambient[0], p.light_ambient[1], p.light_ambient[2], 0.0f);
@@ -1055,7 +856,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
       const int obj = hit_obj[i];
       const unsigned slot_or_path = __float_as_uint(r0.w);
       const int aux = __float_as_int(r1.w);
-      const int bounces = LEVEL == 0 ? 0 : (aux >> 16);
+      // aux of a bounce ray: bits 0-15 the object it left (skipped by the walk), 16-26 bounces so far (the reference's
+      // `depth`), 27-30 RefractionMaterial terms gathered so far, 31 set when the surface it left owes one more
+      const int bounces = LEVEL == 0 ? 0 : ((aux >> 16) & 0x7ff);
+      int n_terms = LEVEL == 0 ? 0 : ((aux >> 27) & 15);
       path = LEVEL == 0 ? i : slot_or_path;
       // the sample slot and pixel of this path
       const unsigned slot = LEVEL == 0 ? slot_or_path : __float_as_uint(((const float4 *) p.rays0)[2 * (size_t) path].w);
@@ -1066,23 +870,44 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
             // RenderThread.java:53-55
             ((float4 *) p.samples)[slot] = make_float4(p.light_ambient[0], p.light_ambient[1], p.light_ambient[2], 0.0f);
          } else {
-            // ReflectionMaterial.java:19-20
+            // ReflectionMaterial.java:19-20, RefractionMaterial.java:39-40
             mat[0] = p.light_ambient[0];
             mat[1] = p.light_ambient[1];
             mat[2] = p.light_ambient[2];
             have_mat = true;
          }
       } else {
-         const DevMaterial &m = p.sc.objs[obj].mat;
+         const DevObject &ob = p.sc.objs[obj];
+         const DevMaterial &m = ob.mat;
          const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z), D = mk3(r1.x, r1.y, r1.z);
-         if (m.kind == 2u && bounces < p.max_mirror_bounces) {
+         if (LEVEL == 1 && aux < 0) {
+            // the refracting surface this ray left was entered from outside and the ray hit something:
+            // RefractionMaterial.java:43-53's term, kept as its exponent until the path ends
+            const float4 pp = ((const float4 *) p.refr_parent)[path];
+            const float *pd = p.sc.objs[aux & 0xffff].mat.diffuse;
+            const float distance = distance3(mk3(pp.x, pp.y, pp.z), P);
+            const float f = 0.15f * -distance;
+            ((float4 *) p.refr_terms)[(size_t) path * MAX_REFRACTION_TERMS + n_terms] = make_float4(pd[0] * f, pd[1] * f, pd[2] * f, 0.0f);
+            n_terms++;
+         }
+         const bool cut = ob.kind != OBJ_MESH && bounces >= p.max_recursion_depth;   // SceneObject.java:65-67; KDTree.java:77-80 has none
+         if (!cut && m.kind == MAT_REFLECTION && bounces < p.max_mirror_bounces) {
             // ReflectionMaterial.java:16-17 + Camera.java:196-200 (offset origin, Ray ctor normalises again)
             sec_o = add3(P, scale3(N, p.sc.epsilon));
             sec_d = normalize3(reflect3(N, D));
-            sec_aux = (obj & 0xffff) | ((bounces + 1) << 16);
+            sec_aux = (obj & 0xffff) | ((bounces + 1) << 16) | (n_terms << 27);
             push_sec = true;
             n_sec++;
-         } else if (m.kind == 1u) {
+         } else if (!cut && m.kind == MAT_REFRACTION && bounces < p.max_mirror_bounces && n_terms < MAX_REFRACTION_TERMS) {
+            // RefractionMaterial.java:33-35 + Camera.java:196-200
+            const bool entering = dot3(N, D) <= 0.0f;   // RefractionMaterial.java:43
+            sec_o = add3(P, scale3(N, p.sc.epsilon));
+            sec_d = normalize3(refraction_direction(N, D, p.sc.ext[obj].refraction_index));
+            sec_aux = (obj & 0xffff) | ((bounces + 1) << 16) | (n_terms << 27) | (entering ? (int) 0x80000000 : 0);
+            if (entering) ((float4 *) p.refr_parent)[path] = make_float4(P.x, P.y, P.z, 0.0f);
+            push_sec = true;
+            n_sec++;
+         } else if (!cut && m.kind == MAT_BRDF) {
             // BRDFMaterial.getMaterialColor materials/BRDFMaterial.java:158-167
             const V3 light = mk3(p.light_origin[0], p.light_origin[1], p.light_origin[2]);
             const float lum = brdf_luminocity(p.brdf_dirs, p.brdf_weights + (size_t) m.brdf_id * (size_t) p.n_dirs, p.n_dirs,
@@ -1092,11 +917,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
             hsv[2] = lum;
             hsv_to_rgb(hsv, mat);
             have_mat = true;
+         } else if (!cut && m.kind == MAT_CHECKERBOARD) {
+            checker_color(ob.bmin, ob.bmax, P, p.sc.ext[obj], mat);
+            have_mat = true;
          } else {
+            // ColorInformation.java:35-37; the cut-off and the bounce guards answer with getDiffuse() too
             mat[0] = m.diffuse[0];
             mat[1] = m.diffuse[1];
             mat[2] = m.diffuse[2];
             have_mat = true;
+         }
+      }
+      if (LEVEL == 1 && have_mat && n_terms > 0) {
+         // the path has ended: RefractionMaterial.java:50-52's additions unwind deepest first
+         for (int t = n_terms - 1; t >= 0; t--) {
+            const float4 x = ((const float4 *) p.refr_terms)[(size_t) path * MAX_REFRACTION_TERMS + t];
+            mat[0] = (float) ((double) mat[0] + exp((double) x.x));
+            mat[1] = (float) ((double) mat[1] + exp((double) x.y));
+            mat[2] = (float) ((double) mat[2] + exp((double) x.z));
          }
       }
       if (LEVEL == 0) {

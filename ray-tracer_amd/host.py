@@ -13,7 +13,11 @@ and shading all happen behind include/mi355rt.h.
     materials/ColorInformation        ColorInformation.java     ColorInformation
     materials/BRDFMaterial            BRDFMaterial.java         BRDFMaterial
     materials/ReflectionMaterial      ReflectionMaterial.java   ReflectionMaterial
+    materials/RefractionMaterial      RefractionMaterial.java   RefractionMaterial
+    materials/CheckerboardMaterial    CheckerboardMaterial.java CheckerboardMaterial
     sceneObjects/TriangleMesh         TriangleMesh.java         TriangleMesh
+    sceneObjects/Sphere               Sphere.java               Sphere
+    sceneObjects/Plane                Plane.java                Plane
     Scene                             Scene.java                Scene
     Camera                            Camera.java               Camera
 """
@@ -111,6 +115,9 @@ class ColorInformation:
         m.brdf_id = int(self.brdf_id)
         return m
 
+    def _abi_material_ext(self):
+        return _abi.MaterialExt()
+
 
 class BRDFMaterial(ColorInformation):
     """BRDFMaterial(materialID, color).  The parsed CUReT tables are handed over once through
@@ -152,6 +159,90 @@ class ReflectionMaterial(ColorInformation):
         super().__init__(diffuse, 100.0)
 
 
+class RefractionMaterial(ColorInformation):
+    """RefractionMaterial(diffuse, refractionIndex): ColorInformation(diffuse, 100) whose colour is what the
+    refracted ray sees plus an absorption term (RefractionMaterial.java:29-59)."""
+    kind = _abi.MAT_REFRACTION
+    INDEX_OF_AIR = 1.00029
+    INDEX_OF_GLASS = 1.52
+    INDEX_OF_ICE = 1.31
+    INDEX_OF_WATER = 1.33
+    INDEX_OF_QUARTZ = 1.46
+    INDEX_OF_SAPPHIRE = 1.77
+    INDEX_OF_DIAMOND = 2.417
+
+    def __init__(self, diffuse, refractionIndex):
+        super().__init__(diffuse, 100.0)
+        self.refractionIndex = float(refractionIndex)
+
+    def _abi_material_ext(self):
+        e = _abi.MaterialExt()
+        e.refraction_index = self.refractionIndex
+        return e
+
+
+class CheckerboardMaterial(ColorInformation):
+    """CheckerboardMaterial(c1, c2, cellWidth, cellHeight, cellDepth): ColorInformation() (all black, shininess
+    20) whose colour alternates between c1 and c2 over the object's bounds (CheckerboardMaterial.java:21-49)."""
+    kind = _abi.MAT_CHECKERBOARD
+
+    def __init__(self, c1, c2, cellWidth, cellHeight, cellDepth):
+        super().__init__()
+        self.color1 = tuple(float(v) for v in c1)
+        self.color2 = tuple(float(v) for v in c2)
+        self.cell = (float(cellWidth), float(cellHeight), float(cellDepth))
+
+    def _abi_material_ext(self):
+        e = _abi.MaterialExt()
+        e.checker_color1[:] = self.color1
+        e.checker_color2[:] = self.color2
+        e.checker_cell[:] = self.cell
+        return e
+
+
+class Sphere:
+    """Sphere(radius, origin, colorInfo) (Sphere.java:15-22); intersected analytically behind its BoundingSphere."""
+
+    def __init__(self, radius=1.0, origin=(0.0, 0.0, 0.0), colorInfo=None):
+        self.radius = float(radius)
+        self.origin = tuple(float(v) for v in origin)
+        self.colorInfo = colorInfo if colorInfo is not None else ColorInformation()
+        self.computeKDTree = True
+
+    def getBoundingVolume(self):
+        return self
+
+    def _fill(self, desc, keep):
+        desc.kind = _abi.OBJ_SPHERE
+        desc.center[:] = self.origin
+        desc.radius = self.radius
+
+
+class Plane:
+    """Plane(corners, colorInfo) (Plane.java:28-76): three or four corners; the hit region is the corners'
+    axis-aligned box on the plane, as Plane.pointInPolygon has it."""
+
+    def __init__(self, corners=None, colorInfo=None):
+        if corners is None:   # Plane() (Plane.java:78-80)
+            corners = [(-1, 0, -1), (-1, 0, 1), (1, 0, -1), (1, 0, 1)]
+            colorInfo = CheckerboardMaterial((1.0, 1.0, 0.0), (0.0, 0.0, 1.0), 1.0, 1.0, 1.0)
+        c = _f32(corners).reshape(-1, 3)
+        if c.shape[0] < 3:
+            raise ValueError("The array of corner values must contain three or more vertices")   # Plane.java:33-35
+        self.corners = c[:4]
+        self.colorInfo = colorInfo if colorInfo is not None else ColorInformation()
+        self.computeKDTree = True
+
+    def getBoundingVolume(self):
+        return self
+
+    def _fill(self, desc, keep):
+        desc.kind = _abi.OBJ_PLANE
+        flat = self.corners.reshape(-1)
+        desc.corners[: flat.size] = [float(v) for v in flat]
+        desc.n_corners = self.corners.shape[0]
+
+
 class TriangleMesh:
     """TriangleMesh(modelLocation, colorInfo, computeKDTree).
 
@@ -172,6 +263,16 @@ class TriangleMesh:
 
     def getBoundingVolume(self):
         return self
+
+    def _fill(self, desc, keep):
+        v, i, n = self.vertices, self.indices, self.normals
+        keep += [v, i, n]
+        desc.kind = _abi.OBJ_MESH
+        desc.mesh.vertices = _fp(v)
+        desc.mesh.normals = _fp(n) if n is not None else None
+        desc.mesh.indices = _ip(i)
+        desc.mesh.n_vertices = v.shape[0]
+        desc.mesh.n_faces = i.shape[0]
 
 
 def load_ply(path):
@@ -219,21 +320,16 @@ class Scene:
         self._lib = _abi.load()
         self._handle = C.c_void_p()
 
-        descs = (_abi.MeshDesc * max(len(self.objects), 1))()
+        descs = (_abi.ObjectDesc * max(len(self.objects), 1))()
         keep = []
         use_kd = True
-        for k, mesh in enumerate(self.objects):
-            v, i, n = mesh.vertices, mesh.indices, mesh.normals
-            keep += [v, i, n]
-            descs[k].vertices = _fp(v)
-            descs[k].normals = _fp(n) if n is not None else None
-            descs[k].indices = _ip(i)
-            descs[k].n_vertices = v.shape[0]
-            descs[k].n_faces = i.shape[0]
-            descs[k].material = mesh.colorInfo._abi_material()
-            use_kd = use_kd and mesh.computeKDTree
+        for k, obj in enumerate(self.objects):   # TriangleMesh, Sphere or Plane, in Scene.objects order
+            obj._fill(descs[k], keep)
+            descs[k].mesh.material = obj.colorInfo._abi_material()
+            descs[k].ext = obj.colorInfo._abi_material_ext()
+            use_kd = use_kd and obj.computeKDTree
         opts = _abi.BuildOpts(RTStatics.MAX_DEPTH, RTStatics.MAX_CHILDREN, 1 if use_kd else 0, int(device))
-        _abi.check(self._lib.mi355rt_scene_create(descs, len(self.objects), C.byref(opts), C.byref(self._handle)))
+        _abi.check(self._lib.mi355rt_scene_create_objects(descs, len(self.objects), C.byref(opts), C.byref(self._handle)))
         if any(isinstance(m.colorInfo, BRDFMaterial) for m in self.objects):
             if BRDFMaterial.tables is None:
                 raise ValueError("BRDFMaterial.setTables(angles, weights) must be called before building a BRDF scene")

@@ -13,20 +13,37 @@ def to_orc_material(ci):
                            specular=ci.specular, ambient=ci.ambient, emission=ci.emission)
 
 
+def to_orc_ext(ci):
+    e = ci._abi_material_ext()
+    return oracle.material_ext(e.refraction_index, tuple(e.checker_color1), tuple(e.checker_color2), tuple(e.checker_cell))
+
+
+def _both_sides(entry, use_kdtree):
+    """(host object, oracle entry) of one Scene.objects entry: a (v, i, n, ColorInformation) mesh, an rt.Sphere or an rt.Plane."""
+    if isinstance(entry, rt.Sphere):
+        return entry, oracle.sphere(entry.origin, entry.radius, to_orc_material(entry.colorInfo), to_orc_ext(entry.colorInfo))
+    if isinstance(entry, rt.Plane):
+        return entry, oracle.plane(entry.corners.tolist(), to_orc_material(entry.colorInfo), to_orc_ext(entry.colorInfo))
+    v, i, n, ci = entry
+    return (rt.TriangleMesh((v, i) if n is None else (v, i, n), ci, use_kdtree),
+            (v, i, n, to_orc_material(ci), to_orc_ext(ci)))
+
+
 class Pair:
     """One scene built on both sides."""
 
     def __init__(self, meshes, orientation=(0, 0, 0), fov=15.0, phong=True, light=None, brdf_tables=None,
                  use_kdtree=True):
-        # meshes: list of (vertices, indices, normals-or-None, ColorInformation)
+        # meshes: list of (vertices, indices, normals-or-None, ColorInformation) and rt.Sphere / rt.Plane objects
         light = light or LIGHT
         self.light = rt.Light(light["origin"], light["emission"], light["ambient"])
         if brdf_tables is not None:
             rt.BRDFMaterial.setTables(*brdf_tables)
-        tms = [rt.TriangleMesh((v, i) if n is None else (v, i, n), ci, use_kdtree) for (v, i, n, ci) in meshes]
+        sides = [_both_sides(e, use_kdtree) for e in meshes]
+        tms = [h for h, _ in sides]
         lm = rt.PhongLightingModel(self.light, tms) if phong else rt.LightingModel()
         self.scene = rt.Scene(tms, self.light, orientation, lm, fov)
-        self.oscene = oracle.OracleScene([(v, i, n, to_orc_material(ci)) for (v, i, n, ci) in meshes],
+        self.oscene = oracle.OracleScene([o for _, o in sides],
                                          max_depth=rt.RTStatics.MAX_DEPTH, max_children=rt.RTStatics.MAX_CHILDREN,
                                          use_kdtree=use_kdtree)
         if brdf_tables is not None:
@@ -37,12 +54,16 @@ class Pair:
         self.eps = self.oscene.epsilon()
         assert np.float32(self.eps) == np.float32(rt.RTStatics.EPSILON)
 
-    def cameras(self, W, H, ms=1, brdf_samples=1, seed=0):
+    def cameras(self, W, H, ms=1, brdf_samples=1, seed=0, origin=None):
         cam = rt.Camera(self.scene, ms, brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=seed)
         ocam = self.oscene.camera(self.orientation, self.fov, rt.RTStatics.NEAR_PLANE, W, H)
+        if origin is not None:   # a hand-placed camera (the constructor's own placement is compared by the caller first)
+            cam._cam.origin[:] = origin
+            ocam.origin[:] = origin
         ost = oracle.settings(epsilon=self.eps, ms=ms, brdf_samples=brdf_samples, lighting=1 if self.phong else 0, seed=seed,
                               light_origin=self.light.origin, light_emission=self.light.emission,
-                              light_ambient=self.light.ambient, bounces=rt.RTStatics.MAX_MIRROR_BOUNCES)
+                              light_ambient=self.light.ambient, bounces=rt.RTStatics.MAX_MIRROR_BOUNCES,
+                              max_recursion_depth=rt.RTStatics.MAX_RECURSION_DEPTH)
         return cam, ocam, ost
 
     def close(self):

@@ -140,3 +140,141 @@ def camera(minmax, orientation, fov, near, W, H):   # Camera.java:50-81
     vw = f32((f32(W) / f32(H) if W >= H else f32(1.0)) * f32(near))
     vh = f32((f32(1.0) if W >= H else f32(H) / f32(W)) * f32(near))
     return origin, m, vw, vh
+
+
+# ---------------------------------------------------------------- analytic objects
+
+def least_positive(i, j):   # RTStatics.java:82-100
+    if i < 0 and j < 0:
+        return f32(-1)
+    if i < 0 and j > 0:
+        return j
+    if i > 0 and j < 0:
+        return i
+    return i if i < j else j
+
+
+def _sphere_w(o, d, c, radius, first_threshold):   # Sphere.java:38-99 / BoundingSphere.java:34-95
+    f64 = np.float64
+    with np.errstate(all="ignore"):
+        a = f32(f64(d[0]) ** 2 + f64(d[1]) ** 2 + f64(d[2]) ** 2)
+        e = [f32(o[k] - c[k]) for k in range(3)]
+        b = f32(f32(2) * f32(f32(f32(d[0] * e[0]) + f32(d[1] * e[1])) + f32(d[2] * e[2])))
+        cc = f32(f64(e[0]) ** 2 + f64(e[1]) ** 2 + f64(e[2]) ** 2 - f64(radius) ** 2)
+        b24c = f32(f32(f64(b) ** 2) - f32(f32(4) * cc))
+        wplus = f32(f32(f64(-b) + np.sqrt(f64(b24c))) / f32(f32(2) * a))
+        wminus = f32(f32(f64(-b) - np.sqrt(f64(b24c))) / f32(f32(2) * a))
+        if b24c < 0:
+            return f32(-1)
+        w = least_positive(wplus, wminus)
+        if w <= 0:
+            return f32(-1)
+
+        def dist(t):
+            q = [f32(o[k] + f32(d[k] * t)) for k in range(3)]
+            x = [f32(o[k] - q[k]) for k in range(3)]
+            return f32(np.sqrt(f64(f32(f32(f32(x[0] * x[0]) + f32(x[1] * x[1])) + f32(x[2] * x[2])))))
+        if w == wplus:
+            nd = dist(wplus)
+            if f64(nd) < first_threshold and wminus > 0:
+                w = wminus
+            elif f64(nd) < first_threshold and wminus < 0:
+                return f32(-1)
+        elif w == wminus:
+            md = dist(wminus)
+            if f64(md) < 0.01 and wplus > 0:
+                w = wplus
+            elif f64(md) < 0.01 and wplus < 0:
+                return f32(-1)
+        return w if w > 0 else f32(-1)
+
+
+def bounding_sphere_intersects(o, d, c, radius, eps):   # BoundingSphere.java:29-102
+    return bool(_sphere_w(o, d, c, radius, np.float64(f32(eps))) > 0)
+
+
+def sphere_intersection(o, d, c, radius, eps):   # Sphere.java:29-112 -> (point, normal, w) or None
+    s = f32(f32(eps) * f32(2))
+    origin = [f32(o[k] + f32(d[k] * s)) for k in range(3)]
+    w = _sphere_w(origin, d, c, radius, 0.01)
+    if not w > 0:
+        return None
+    p = [f32(f32(d[k] * w) + origin[k]) for k in range(3)]
+    return p, vnormalize(vsub(p, c)), w
+
+
+def plane_setup(corners):   # Plane.java:28-76 -> (A, B, C, D, normal, minmax6)
+    c = [[f32(x) for x in corners[i if i < len(corners) else 2]] for i in range(4)]   # :60-63
+
+    def m(a, b):
+        return f32(a * b)
+
+    def s3(a, b, cc):
+        return f32(f32(a + b) + cc)
+    A = s3(m(c[0][1], f32(c[1][2] - c[2][2])), m(c[1][1], f32(c[2][2] - c[0][2])), m(c[2][1], f32(c[0][2] - c[1][2])))
+    B = s3(m(c[0][2], f32(c[1][0] - c[2][0])), m(c[1][2], f32(c[2][0] - c[0][0])), m(c[2][2], f32(c[0][0] - c[1][0])))
+    C = s3(m(c[0][0], f32(c[1][1] - c[2][1])), m(c[1][0], f32(c[2][1] - c[0][1])), m(c[2][0], f32(c[0][1] - c[1][1])))
+    D = f32(-s3(m(c[0][0], f32(m(c[1][1], c[2][2]) - m(c[2][1], c[1][2]))), m(c[1][0], f32(m(c[2][1], c[0][2]) - m(c[0][1], c[2][2]))),
+                m(c[2][0], f32(m(c[0][1], c[1][2]) - m(c[1][1], c[0][2])))))
+    mm = [min(c[i][k] for i in range(4)) for k in range(3)] + [max(c[i][k] for i in range(4)) for k in range(3)]
+    return A, B, C, D, vnormalize([A, B, C]), mm
+
+
+def plane_intersection(o, d, corners, eps):   # Plane.java:87-154 -> (point, normal, w) or None
+    A, B, C, D, pn, mm = plane_setup(corners)
+    eps = f32(eps)
+    with np.errstate(all="ignore"):
+        s = f32(eps * f32(2))
+        origin = [f32(o[k] + f32(d[k] * s)) for k in range(3)]
+        vD = vdot(pn, d)
+        if vD > eps:
+            pn = [f32(-x) for x in pn]
+            vD = vdot(pn, d)
+        if not (vD <= -eps or vD >= eps):
+            return None
+        num = f32(f32(f32(f32(A * origin[0]) + f32(B * origin[1])) + f32(C * origin[2])) + D)
+        den = f32(f32(f32(A * d[0]) + f32(B * d[1])) + f32(C * d[2]))
+        t = f32(f32(-num) / den)
+        if not t > -eps:
+            return None
+        rD = list(d)
+        if vD > -eps:
+            rD = [f32(-x) for x in rD]
+        pI = [f32(origin[k] + f32(rD[k] * t)) for k in range(3)]
+        for k in range(3):
+            if not (pI[k] >= f32(mm[k] - eps) and pI[k] <= f32(mm[3 + k] + eps)):
+                return None
+        tv = vsub(pI, origin)
+        w = f32(np.sqrt(np.float64(f32(f32(f32(tv[0] * tv[0]) + f32(tv[1] * tv[1])) + f32(tv[2] * tv[2])))))
+        return pI, pn, w
+
+
+def refraction_direction(n, d, index):   # RefractionMaterial.java:61-95
+    f64 = np.float64
+    aether = f32(1.00029)
+    sn = list(n)
+    cos_i = f64(vdot(sn, d))
+    if cos_i <= 0:
+        nn = f64(f32(f32(index) / aether))
+        cos_i = -cos_i
+    else:
+        nn = f64(f32(aether / f32(index)))
+        sn = [f32(-x) for x in sn]
+    root = 1.0 - nn * nn * (1.0 - cos_i * cos_i)
+    if root < 0:
+        return reflection_direction(sn, d)
+    k1 = f32(nn)
+    k2 = f32(nn * cos_i - math.sqrt(root))
+    out = [f32(f32(d[k] * k1) + f32(sn[k] * k2)) for k in range(3)]
+    return vnormalize(out)
+
+
+def checker_color(mm, p, c1, c2, cell):   # CheckerboardMaterial.java:21-49
+    span = [f32(f32(mm[3 + k]) - f32(mm[k])) for k in range(3)]
+    dist = [f32(f32(p[k]) - f32(mm[k])) for k in range(3)]
+    if any(dist[k] < 0 or dist[k] > span[k] for k in range(3)):
+        return [f32(0)] * 3
+    x, y, z = (int(math.floor(float(f32(dist[k] / f32(cell[k]))))) for k in range(3))
+    one = (x % 2 == 0 and y % 2 == 0 and z % 2 == 0) or (x % 2 == 1 and y % 2 == 0 and z % 2 == 1) or \
+        (x % 2 == 0 and y % 2 == 1 and z % 2 == 1)
+    return [f32(v) for v in (c1 if one else c2)]

@@ -27,6 +27,16 @@ class MeshDesc(C.Structure):
                 ("n_faces", C.c_uint32), ("material", Material)]
 
 
+class MaterialExt(C.Structure):
+    _fields_ = [("refraction_index", C.c_float), ("checker_color1", C.c_float * 3), ("checker_color2", C.c_float * 3),
+                ("checker_cell", C.c_float * 3)]
+
+
+class ObjectDesc(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("mesh", MeshDesc), ("ext", MaterialExt), ("center", C.c_float * 3),
+                ("radius", C.c_float), ("corners", C.c_float * 12), ("n_corners", C.c_uint32)]
+
+
 class BuildOpts(C.Structure):
     _fields_ = [("max_depth", C.c_int32), ("max_children", C.c_int32), ("use_kdtree", C.c_int32), ("device", C.c_int32)]
 
@@ -63,6 +73,13 @@ def lib():
             build()
         L = C.CDLL(LIB_PATH)
         L.orc_scene_create.argtypes = [C.POINTER(MeshDesc), C.c_uint32, C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]
+        L.orc_scene_create_objects.argtypes = [C.POINTER(ObjectDesc), C.c_uint32, C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]
+        L.orc_sphere_intersection.argtypes = [fp, fp, fp, C.c_float, C.c_float, C.c_int, fp]
+        L.orc_plane_intersection.argtypes = [fp, fp, fp, C.c_uint32, C.c_float, fp]
+        L.orc_refraction_direction.argtypes = [fp, fp, C.c_float, fp]
+        L.orc_refraction_direction.restype = None
+        L.orc_checker_color.argtypes = [fp, fp, C.POINTER(MaterialExt), fp]
+        L.orc_checker_color.restype = None
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_scene_destroy.restype = None
         L.orc_scene_set_brdf.argtypes = [C.c_void_p, fp, C.c_int32, fp, C.c_int32]
@@ -141,30 +158,68 @@ def material(kind=0, diffuse=(1, 1, 1), shininess=20.0, brdf_id=0, specular=None
     return m
 
 
+def material_ext(refraction_index=0.0, color1=(0, 0, 0), color2=(0, 0, 0), cell=(1, 1, 1)):
+    e = MaterialExt()
+    e.refraction_index = refraction_index
+    e.checker_color1[:] = color1
+    e.checker_color2[:] = color2
+    e.checker_cell[:] = cell
+    return e
+
+
+def sphere(center, radius, mat, ext=None):
+    """A Sphere(radius, origin, colorInfo) entry for OracleScene."""
+    return ("sphere", tuple(center), float(radius), mat, ext)
+
+
+def plane(corners, mat, ext=None):
+    """A Plane(corners, colorInfo) entry for OracleScene."""
+    return ("plane", [tuple(c) for c in corners], None, mat, ext)
+
+
 class OracleScene:
-    """meshes: list of (vertices, indices, normals-or-None, Material)."""
+    """objects: list of (vertices, indices, normals-or-None, Material) meshes and sphere(...) / plane(...) entries,
+    in Scene.objects order."""
 
     def __init__(self, meshes, max_depth=20, max_children=5, use_kdtree=True):
         L = lib()
         self._keep = []
-        descs = (MeshDesc * max(len(meshes), 1))()
-        for k, (v, i, n, m) in enumerate(meshes):
+        descs = (ObjectDesc * max(len(meshes), 1))()
+        for k, entry in enumerate(meshes):
+            if isinstance(entry[0], str):
+                kind, geo, radius, m, ext = entry
+                descs[k].kind = 1 if kind == "sphere" else 2
+                if kind == "sphere":
+                    descs[k].center[:] = geo
+                    descs[k].radius = radius
+                else:
+                    flat = [float(x) for c in geo for x in c]
+                    descs[k].corners[: len(flat)] = flat
+                    descs[k].n_corners = len(geo)
+                descs[k].mesh.material = m
+                if ext is not None:
+                    descs[k].ext = ext
+                continue
+            v, i, n, m = entry[:4]
             v = f32(v).reshape(-1, 3)
             i = np.ascontiguousarray(np.asarray(i, dtype=np.int32)).reshape(-1, 3)
             n = None if n is None else f32(n).reshape(-1, 3)
             self._keep += [v, i, n]
-            descs[k].vertices = P(v)
-            descs[k].normals = P(n) if n is not None else None
-            descs[k].indices = PI(i)
-            descs[k].n_vertices = v.shape[0]
-            descs[k].n_faces = i.shape[0]
-            descs[k].material = m
-        self.n_vertices = [d.n_vertices for d in descs[: len(meshes)]]
+            descs[k].kind = 0
+            descs[k].mesh.vertices = P(v)
+            descs[k].mesh.normals = P(n) if n is not None else None
+            descs[k].mesh.indices = PI(i)
+            descs[k].mesh.n_vertices = v.shape[0]
+            descs[k].mesh.n_faces = i.shape[0]
+            descs[k].mesh.material = m
+            if len(entry) > 4 and entry[4] is not None:
+                descs[k].ext = entry[4]
+        self.n_vertices = [d.mesh.n_vertices for d in descs[: len(meshes)]]
         opts = BuildOpts(max_depth, max_children, 1 if use_kdtree else 0, -1)
         self.h = C.c_void_p()
-        rc = L.orc_scene_create(descs, len(meshes), C.byref(opts), C.byref(self.h))
+        rc = L.orc_scene_create_objects(descs, len(meshes), C.byref(opts), C.byref(self.h))
         if rc != 0:
-            raise RuntimeError("orc_scene_create failed: %d" % rc)
+            raise RuntimeError("orc_scene_create_objects failed: %d" % rc)
         self.n_objs = len(meshes)
 
     def set_brdf(self, angles, weights):
@@ -231,12 +286,12 @@ class OracleScene:
 
 
 def settings(epsilon=1e-15, near=0.01, far=3000.0, ms=1, brdf_samples=1, lighting=1, seed=0,
-             light_origin=(0, 100, 100), light_emission=(0.3, 0.3, 0.3), light_ambient=(0.5, 0.5, 0.9), bounces=64):
+             light_origin=(0, 100, 100), light_emission=(0.3, 0.3, 0.3), light_ambient=(0.5, 0.5, 0.9), bounces=64, max_recursion_depth=5):
     st = Settings()
     st.epsilon = epsilon
     st.near_plane = near
     st.far_plane = far
-    st.max_recursion_depth = 5
+    st.max_recursion_depth = max_recursion_depth
     st.multi_samples = ms
     st.brdf_samples = brdf_samples
     st.lighting_model = lighting

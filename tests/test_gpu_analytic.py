@@ -1,0 +1,190 @@
+"""Spheres, planes, RefractionMaterial and CheckerboardMaterial: the reference's own Whitted and
+Cornell-Phong scenes (RayTracer.java:111-116,147-149,155-235) and mixed mesh + analytic scenes, HIP path vs oracle
+through the C ABI.  Same bar as the mesh tests: hit ids and w bit-exact, radiance within 1e-3 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+YELLOW, RED, BLUE, GRAY, GREEN, CYAN, WHITE = (1, 1, 0), (1, 0, 0), (0, 0, 1), (128 / 255.0,) * 3, (0, 1, 0), (0, 1, 1), (1, 1, 1)
+
+
+def whitted_objects(rt, use_brdfs):
+    """RayTracer.getWhittedObjects (RayTracer.java:155-167)."""
+    plane = rt.Plane([(-50, 0, -100), (-50, -40, 25), (50, -40, 25), (50, 0, -100)], rt.CheckerboardMaterial(YELLOW, RED, 10.0, 10.0, 10.0))
+    blue = rt.ReflectionMaterial(BLUE)
+    glass = rt.RefractionMaterial(GRAY, rt.RefractionMaterial.INDEX_OF_GLASS)
+    s1 = rt.Sphere(5, (0, -12, 0), rt.BRDFMaterial(15, GREEN) if use_brdfs else glass)
+    s2 = rt.Sphere(3, (5, -15, -10), rt.BRDFMaterial(16, CYAN) if use_brdfs else blue)
+    return [plane, s1, s2]
+
+
+def cornell_box(rt, use_spheres, use_whitted_materials):
+    """RayTracer.getCornellBox (RayTracer.java:176-235)."""
+    white, white2 = rt.ColorInformation((0.75, 0.75, 0.75)), rt.ColorInformation((0.65, 0.65, 0.65))
+    red, green = rt.ColorInformation((0.63, 0.06, 0.04)), rt.ColorInformation((0.15, 0.48, 0.09))
+    blue = rt.ColorInformation((0.392, 0.584, 0.93))
+    mirror, glass = rt.ReflectionMaterial(WHITE), rt.RefractionMaterial(BLUE, rt.RefractionMaterial.INDEX_OF_GLASS)
+    (x0, y0, z0), (x1, y1, z1) = (-278, -275, -800), (278, 275, 280)
+    objs = [rt.Plane([(x1, y0, z0), (x0, y0, z0), (x0, y0, z1), (x1, y0, z1)], white),    # floor
+            rt.Plane([(x1, y1, z0), (x1, y1, z1), (x0, y1, z1), (x0, y1, z0)], white),    # ceiling
+            rt.Plane([(x1, y0, z1), (x0, y0, z1), (x0, y1, z1), (x1, y1, z1)], white),    # back
+            rt.Plane([(x1, y0, z0), (x0, y0, z0), (x0, y1, z0), (x1, y1, z0)], white),    # front
+            rt.Plane([(x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0)], red),      # left
+            rt.Plane([(x0, y0, z1), (x0, y0, z0), (x0, y1, z0), (x0, y1, z1)], green)]    # right
+    if use_spheres:
+        objs += [rt.Sphere(82.5, (-92, -192.5, -111.5), glass if use_whitted_materials else blue),
+                 rt.Sphere(82.5, (116.5, -192.5, 71.5), mirror if use_whitted_materials else blue)]
+    else:
+        small = [[(-148, -110, -215), (-196, -110, -55), (-32, -110, -8), (12, -110, -166)],
+                 [(12, -275, -166), (12, -110, -166), (-32, -110, -8), (-32, -275, -8)],
+                 [(-148, -275, -215), (-148, -110, -215), (12, -110, -166), (12, -275, -166)],
+                 [(-196, -275, -55), (-196, -110, -55), (-148, -110, -215), (-148, -275, -215)],
+                 [(-32, -275, -8), (-32, -110, -8), (-196, -110, -55), (-196, -275, -55)]]
+        large = [[(145, 55, -33), (-13, 55, 16), (36, 55, 176), (194, 55, 126)],
+                 [(145, -275, -33), (145, 55, -33), (194, 55, 126), (194, -275, 126)],
+                 [(194, -275, 126), (194, 55, 126), (36, 55, 176), (36, -275, 176)],
+                 [(36, -275, 176), (36, 55, 176), (-13, 55, 16), (-13, -275, 16)],
+                 [(-13, -275, 16), (-13, 55, 16), (145, 55, -33), (145, -275, -33)]]
+        objs += [rt.Plane(c, white2) for c in small + large]
+    return objs
+
+
+CORNELL_LIGHT = dict(origin=(0.0, 270.0, 0.0), emission=(0.75, 0.75, 0.75), ambient=(0.75, 0.75, 0.75))   # RayTracer.java:109
+
+
+def _check(pair, W, H, ms=1, brdf_samples=1, seed=0, rtol=1e-3, origin=None, min_hit=0.05):
+    from helpers import compare_frames
+    cam, ocam, ost = pair.cameras(W, H, ms=ms, brdf_samples=brdf_samples, seed=seed, origin=origin)
+    if origin is None:
+        np.testing.assert_array_equal(np.array(ocam.origin[:], dtype=np.float32), cam.origin)
+    np.testing.assert_array_equal(np.array(ocam.rotation[:], dtype=np.float32).reshape(3, 3), cam.rotation)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=8, want_stats=True)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, rtol=rtol)
+    assert ids_equal, "%d pixels differ in hit id" % n_diff
+    assert w_equal
+    assert max_rel <= rtol, max_rel
+    assert float((o["hit_obj"] >= 0).mean()) >= min_hit
+    return o
+
+
+def test_whitted_scene_phong(rt):
+    """Scenes.WHITTED_SCENE (RayTracer.java:111-113): checkerboard floor, glass sphere, mirror sphere, Phong + shadows."""
+    from helpers import Pair
+    pair = Pair(whitted_objects(rt, False), orientation=(0, 0, 0), fov=35.0, phong=True)
+    assert np.float32(pair.eps) == np.float32(1e-3)
+    o = _check(pair, 320, 240, ms=2, seed=3)
+    assert set(np.unique(o["hit_obj"])) == {-1, 0, 1, 2}        # every object and the background are in view
+    assert o["stats"]["secondary_rays"] > 1000 and o["stats"]["shadow_rays"] > 1000
+    pair.close()
+
+
+def test_whitted_scene_brdf(rt):
+    """Scenes.WHITTED_SCENE_BRDF (RayTracer.java:114-116): BRDF spheres 15 and 16, plain lighting model."""
+    from helpers import Pair, synthetic_brdf_tables
+    pair = Pair(whitted_objects(rt, True), orientation=(0, 0, 0), fov=35.0, phong=False, brdf_tables=synthetic_brdf_tables(n_materials=20))
+    _check(pair, 200, 150, brdf_samples=2)
+    pair.close()
+
+
+def test_cornell_box_phong(rt):
+    """Scenes.CORNELL_BOX_PHONG (RayTracer.java:147-149): six walls, a glass and a mirror sphere, cornellLight."""
+    from helpers import Pair
+    pair = Pair(cornell_box(rt, True, True), orientation=(180, 0, 0), fov=15.0, phong=True, light=CORNELL_LIGHT)
+    o = _check(pair, 256, 256, min_hit=0.5)
+    assert {6, 7} <= set(np.unique(o["hit_obj"]))               # both spheres are seen
+    pair.close()
+
+
+def test_cornell_box_blocks_phong(rt):
+    """The sixteen planes of getCornellBox(false, ...) under the Phong model (the reference lights them with its
+    unfinished photon mapper, which is out of scope)."""
+    from helpers import Pair
+    pair = Pair(cornell_box(rt, False, False), orientation=(180, 0, 0), fov=15.0, phong=True, light=CORNELL_LIGHT)
+    o = _check(pair, 192, 192, ms=2, seed=9, min_hit=0.5)
+    assert len(set(np.unique(o["hit_obj"])) - {-1}) >= 8
+    pair.close()
+
+
+def test_mesh_between_analytic_objects(rt):
+    """A mirror mesh, a glass mesh and a BRDF mesh among spheres and planes: object order decides ties and the mirror /
+    refraction skip, so meshes sit before, between and after the analytic objects."""
+    from helpers import Pair, synthetic_brdf_tables
+    v1, i1 = rt.meshgen.blob(3000, span=8.0, seed=2)
+    v2, i2 = rt.meshgen.blob(2000, span=6.0, seed=5)
+    v3, i3 = rt.meshgen.blob(1500, span=5.0, seed=8)
+    objs = [(v1 + np.float32([-9, 0, 0]), i1, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))),
+            rt.Plane([(-30, -6, -30), (-30, -6, 30), (30, -6, 30), (30, -6, -30)], rt.CheckerboardMaterial(YELLOW, BLUE, 4.0, 1.0, 4.0)),
+            (v2 + np.float32([0, 0, 4]), i2, None, rt.RefractionMaterial((0.4, 0.6, 0.8), rt.RefractionMaterial.INDEX_OF_WATER)),
+            rt.Sphere(3.5, (9, 0, 0), rt.RefractionMaterial(GRAY, rt.RefractionMaterial.INDEX_OF_DIAMOND)),
+            rt.Sphere(2.0, (0, 5, -6), rt.ReflectionMaterial(WHITE)),
+            (v3 + np.float32([3, -2, -8]), i3, None, rt.BRDFMaterial(2, (0.2, 0.8, 0.3))),
+            rt.Plane([(-30, -6, -30), (30, -6, -30), (30, 30, -30), (-30, 30, -30)], rt.ColorInformation((0.7, 0.3, 0.3)))]
+    pair = Pair(objs, orientation=(0, 10, 0), fov=25.0, phong=True, brdf_tables=synthetic_brdf_tables())
+    o = _check(pair, 256, 192, ms=2, seed=21, min_hit=0.2)
+    assert len(set(np.unique(o["hit_obj"])) - {-1}) >= 6
+    pair.close()
+
+
+def test_trace_rays_mixed_scene(rt, orc):
+    """Camera.getClosestIntersection for ray batches over a mixed scene: object, w, point and normal bit for bit."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(2500, span=6.0, seed=3)
+    objs = [rt.Sphere(2.0, (4, 1, 0), rt.ColorInformation(WHITE)), (v, i, None, rt.ColorInformation(WHITE)),
+            rt.Plane([(-8, -4, -8), (-8, -4, 8), (8, -4, 8)], rt.ColorInformation(WHITE)),
+            rt.Sphere(1.0, (-4, 0, 1), rt.ColorInformation(WHITE))]
+    pair = Pair(objs, fov=20.0, phong=False)
+    cam, ocam, ost = pair.cameras(8, 8)
+    rs = np.random.RandomState(77)
+    n = 40000
+    o = rs.uniform(-12, 12, (n, 3)).astype(np.float32)
+    d = (rs.uniform(-4, 4, (n, 3)).astype(np.float32) - o).astype(np.float32)
+    o[: n // 8] = (np.float32([4, 1, 0]) + 2.0 * d[: n // 8] / np.linalg.norm(d[: n // 8], axis=1, keepdims=True)).astype(np.float32)   # on a sphere
+    g = cam.getClosestIntersection(o, d)
+    r = pair.oscene.trace(ost, o, d)
+    np.testing.assert_array_equal(g["object"], r["object"])
+    np.testing.assert_array_equal(g["face"], r["face"])
+    hit = r["object"] >= 0
+    assert 0.2 < hit.mean() < 0.95 and set(np.unique(r["object"])) == {-1, 0, 1, 2, 3}
+    for key in ("w", "point", "normal"):
+        np.testing.assert_array_equal(g[key][hit].view(np.uint32), r[key][hit].view(np.uint32))
+    pair.close()
+
+
+def test_refraction_term_guard_and_depth(rt):
+    """Twelve glass panes in a row with the recursion cut-off lifted: the path gathers MI355RT_MAX_REFRACTION_TERMS
+    absorption terms and the ninth pane answers with its diffuse colour; with the reference's depth of 5 the
+    cut-off comes first."""
+    from helpers import Pair
+    panes = [rt.Plane([(-20, -20, -2.0 * k), (20, -20, -2.0 * k), (20, 20, -2.0 * k), (-20, 20, -2.0 * k)],
+                      rt.RefractionMaterial((0.1 + 0.05 * k, 0.5, 0.9 - 0.05 * k), rt.RefractionMaterial.INDEX_OF_GLASS)) for k in range(12)]
+    back = rt.Plane([(-40, -40, -30), (40, -40, -30), (40, 40, -30), (-40, 40, -30)], rt.CheckerboardMaterial(YELLOW, RED, 5.0, 5.0, 5.0))
+    saved = rt.RTStatics.MAX_RECURSION_DEPTH
+    try:
+        for depth in (64, 5):
+            rt.RTStatics.MAX_RECURSION_DEPTH = depth
+            pair = Pair(panes + [back], fov=20.0, phong=False)
+            o = _check(pair, 96, 96, origin=(0.5, 0.25, 12.0), min_hit=0.9)
+            centre = o["rgb"][48, 48]
+            if depth == 64:
+                np.testing.assert_array_less(np.float32(1.0), centre)       # several exp() terms were added
+            pair.close()
+    finally:
+        rt.RTStatics.MAX_RECURSION_DEPTH = saved
+
+
+def test_analytic_errors_and_empty(rt):
+    from helpers import Pair
+    with pytest.raises(rt._abi.Mi355rtError) as e:
+        rt.Scene([rt.Plane([(0, 0, 0), (1, 0, 0), (2, 0, 0)], rt.ColorInformation(WHITE))], rt.Light(), (0, 0, 0), rt.LightingModel(), 15.0)
+    assert e.value.code == rt._abi.E_ARG and "colinear" in e.value.message
+    with pytest.raises(ValueError):
+        rt.Plane([(0, 0, 0), (1, 0, 0)], rt.ColorInformation(WHITE))
+    # a lone sphere nobody looks at: every pixel is background
+    pair = Pair([rt.Sphere(1.0, (0, 0, 0), rt.ColorInformation(WHITE))], fov=15.0, phong=True)
+    cam, ocam, ost = pair.cameras(32, 32, origin=(0, 50, 0))
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost)
+    assert (o["hit_id"] == -1).all() and np.array_equal(cam.hit_id.T, o["hit_id"]) and np.array_equal(cam._rgb_rows, o["rgb"])
+    pair.close()

@@ -215,3 +215,130 @@ def test_image_packing_and_normalisation(orc):
     assert (out[0, 1] >> 8) & 0xFF == 0xFF
     g = (np.float32(0.6) - np.float32(0.2)) / (np.float32(1.7) - np.float32(0.2))      # red channel of the last pixel = its value
     assert (out[1, 1] >> 16) & 0xFF == int(np.float64(np.float32(g * np.float32(255.0))) + 0.5)
+
+
+# ---------------------------------------------------------------- analytic objects, hand-derived
+
+def _sphere(orc, o, d, c, radius, eps=1e-3, bounding=0):
+    out = np.zeros(7, dtype=np.float32)
+    rc = orc.lib().orc_sphere_intersection(orc.P(orc.f32(o)), orc.P(orc.f32(d)), orc.P(orc.f32(c)), radius, eps, bounding, orc.P(out))
+    return rc, out
+
+
+def test_sphere_unit_at_origin(orc):
+    # Sphere.java:30-33 advances the origin by 2*EPSILON: z = 4.998; roots of t^2 - 9.996 t + 23.980004: 3.998, 5.998
+    rc, out = _sphere(orc, (0, 0, 5), (0, 0, -1), (0, 0, 0), 1.0)
+    assert rc == 1
+    assert np.allclose(out[:3], (0, 0, 1), atol=2e-6) and np.allclose(out[3:6], (0, 0, 1), atol=1e-6)
+    assert abs(out[6] - 3.998) < 2e-6                      # w is measured from the advanced origin
+    assert _sphere(orc, (0, 2, 5), (0, 0, -1), (0, 0, 0), 1.0)[0] == 0     # b^2 - 4c < 0
+    assert _sphere(orc, (0, 0, 5), (0, 0, 1), (0, 0, 0), 1.0)[0] == 0      # both roots negative (leastPositive -> -1)
+    rc, out = _sphere(orc, (0, 0, 0), (0, 0, -1), (0, 0, 0), 1.0)          # from inside: the positive root
+    assert rc == 1 and np.allclose(out[:3], (0, 0, -1), atol=2e-6) and abs(out[6] - 0.998) < 2e-6
+    # BoundingSphere.intersects does not advance the origin and only answers yes / no
+    assert _sphere(orc, (0, 0, 5), (0, 0, -1), (0, 0, 0), 1.0, bounding=1)[0] == 1
+    assert _sphere(orc, (0, 2, 5), (0, 0, -1), (0, 0, 0), 1.0, bounding=1)[0] == 0
+
+
+def test_sphere_surface_origin_skips_near_root(orc):
+    # a ray leaving the surface inwards: the near root (distance < 0.01 from the origin) is replaced by the far one
+    # (Sphere.java:82-98): origin (0,0,1) on the unit sphere, direction -z -> exits at z = -1, w ~ 2 - 2*eps
+    rc, out = _sphere(orc, (0, 0, 1), (0, 0, -1), (0, 0, 0), 1.0, eps=1e-3)
+    assert rc == 1 and np.allclose(out[:3], (0, 0, -1), atol=3e-6) and abs(out[6] - 1.998) < 3e-6
+    # leaving outwards: near root within 0.01 and the other root negative -> null (Sphere.java:94-96)
+    assert _sphere(orc, (0, 0, 1.001), (0, 0, 1), (0, 0, 0), 1.0, eps=1e-15)[0] == 0
+
+
+def _plane(orc, o, d, corners, eps=1e-3):
+    out = np.zeros(7, dtype=np.float32)
+    c = orc.f32(corners).reshape(-1)
+    rc = orc.lib().orc_plane_intersection(orc.P(orc.f32(o)), orc.P(orc.f32(d)), orc.P(c), len(corners), eps, orc.P(out))
+    return rc, out
+
+
+def test_plane_default_unit_floor(orc):
+    floor = [(-1, 0, -1), (-1, 0, 1), (1, 0, -1), (1, 0, 1)]   # Plane() (Plane.java:78-80): A = C = D = 0, B = 4
+    rc, out = _plane(orc, (0, 2, 0), (0, -1, 0), floor)
+    assert rc == 1 and np.allclose(out[:3], (0, 0, 0), atol=1e-6) and tuple(out[3:6]) == (0, 1, 0) and abs(out[6] - 1.998) < 1e-6
+    rc, out = _plane(orc, (0, -2, 0), (0, 1, 0), floor)          # from below: the normal is flipped towards the ray (:98-101)
+    assert rc == 1 and tuple(out[3:6]) == (0, -1, 0) and abs(out[6] - 1.998) < 1e-6
+    assert _plane(orc, (3, 2, 0), (0, -1, 0), floor)[0] == 0     # outside the corners' box (pointInPolygon)
+    assert _plane(orc, (0, 2, 0), (1, 0, 0), floor)[0] == 0      # parallel
+    assert _plane(orc, (0, 2, 0), (0, 1, 0), floor)[0] == 0      # behind the origin: t < -EPSILON
+    assert _plane(orc, (0, 2, 0), (0, -1, 0), [(0, 0, 0), (1, 0, 0), (2, 0, 0)])[0] == -1   # colinear (Plane.java:56-58)
+    rc, out = _plane(orc, (0.9, 2, 0.9), (0, -1, 0), floor[:3])  # three corners: the box of the triangle, not the triangle
+    assert rc == 1
+
+
+def test_refraction_direction_known(orc):
+    out = np.zeros(3, dtype=np.float32)
+    # head-on: n = 1.52 / 1.00029, cosI = 1, root = 1 -> dir * n + N * (n - 1) = (0, 0, -1)
+    orc.lib().orc_refraction_direction(orc.P(orc.f32((0, 0, 1))), orc.P(orc.f32((0, 0, -1))), 1.52, orc.P(out))
+    assert np.allclose(out, (0, 0, -1), atol=1e-6)
+    # the "entering" branch uses n = index / air > 1, so grazing rays are totally reflected (RefractionMaterial.java:81-82)
+    d = orc.f32((1, 0, -0.5))
+    d /= np.linalg.norm(d)
+    orc.lib().orc_refraction_direction(orc.P(orc.f32((0, 0, 1))), orc.P(d), 1.52, orc.P(out))
+    assert np.allclose(out, (d[0], 0, -d[2]), atol=1e-6)
+    # 45 degrees from behind the surface (cosI > 0): n = air / index, the normal is flipped; Snell in double as a cross-check
+    d = orc.f32((np.sqrt(0.5), 0, np.sqrt(0.5)))
+    orc.lib().orc_refraction_direction(orc.P(orc.f32((0, 0, 1))), orc.P(d), 1.52, orc.P(out))
+    n = 1.00029 / 1.52
+    sin_t = n * np.sqrt(0.5)
+    assert np.allclose(out, (sin_t, 0, np.sqrt(1 - sin_t * sin_t)), atol=1e-6)
+
+
+def test_checkerboard_cells(orc):
+    import ctypes as C
+    mm = orc.f32((0, 0, 0, 10, 0, 10))
+    ext = orc.material_ext(0.0, (1, 1, 0), (1, 0, 0), (1, 1, 1))
+    out = np.zeros(3, dtype=np.float32)
+
+    def col(p):
+        orc.lib().orc_checker_color(orc.P(mm), orc.P(orc.f32(p)), C.byref(ext), orc.P(out))
+        return tuple(out)
+    assert col((0.5, 0, 0.5)) == (1, 1, 0)     # (even, even, even) -> color1
+    assert col((1.5, 0, 0.5)) == (1, 0, 0)     # (odd, even, even)  -> color2
+    assert col((1.5, 0, 1.5)) == (1, 1, 0)     # (odd, even, odd)   -> color1
+    assert col((0.5, 0, 1.5)) == (1, 0, 0)     # (even, even, odd)  -> color2
+    assert col((-0.1, 0, 0.5)) == (0, 0, 0)    # outside the object's bounds -> black (CheckerboardMaterial.java:34-36)
+    assert col((0.5, 0.1, 0.5)) == (0, 0, 0)
+
+
+def _analytic_scene(orc, glass_index=1.52):
+    floor = orc.plane([(-50, 0, -100), (-50, -40, 25), (50, -40, 25), (50, 0, -100)],
+                      orc.material(4, (0, 0, 0), 20.0), orc.material_ext(0, (1, 1, 0), (1, 0, 0), (10, 10, 10)))
+    glass = orc.sphere((0, -12, 0), 5, orc.material(3, (0.5, 0.5, 0.5), 100.0), orc.material_ext(glass_index))
+    mirror = orc.sphere((5, -15, -10), 3, orc.material(2, (0, 0, 1), 100.0))
+    return orc.OracleScene([floor, glass, mirror])
+
+
+def test_whitted_scene_structure(orc):
+    """RayTracer.getWhittedObjects (RayTracer.java:155-167): bounds, EPSILON, and what single rays see."""
+    sc = _analytic_scene(orc)
+    assert sc.epsilon() == np.float32(1e-3)
+    assert tuple(sc.object_info(0)["minmax"]) == (-50, -40, -100, 50, 0, 25)
+    assert tuple(sc.object_info(1)["minmax"]) == (-5, -17, -5, 5, -7, 5)       # BoundingSphere.getMinMax
+    st = orc.settings(epsilon=1e-3, lighting=0, light_ambient=(0.25, 0.5, 0.75))
+    # straight down the z axis at the glass sphere's centre: object 1, w = distance to its near side
+    r = sc.trace(st, [(0, -12, 50)], [(0, 0, -1)])
+    assert r["object"][0] == 1 and abs(r["w"][0] - (45 - 0.002)) < 1e-4 and np.allclose(r["normal"][0], (0, 0, 1), atol=1e-6)
+    # past everything: miss
+    assert sc.trace(st, [(0, 30, 50)], [(0, 0, -1)])["object"][0] == -1
+    # down onto the sloping floor (y = -0.32 (z + 100) => y(-50) = -16): object 0, normal facing up
+    r = sc.trace(st, [(-40, 20, -50)], [(0, -1, 0)])
+    assert r["object"][0] == 0 and abs(r["point"][0][1] + 16.0) < 1e-3 and r["normal"][0][1] > 0.9
+
+
+def test_recursion_cutoff_returns_diffuse(orc):
+    """SceneObject.getColor (SceneObject.java:64-67): at depth >= MAX_RECURSION_DEPTH an analytic object answers with
+    its diffuse colour.  Two facing mirror planes: with depth 1 the second mirror answers (0.2, 0.4, 0.6)."""
+    a = orc.plane([(-10, -10, 0), (10, -10, 0), (10, 10, 0), (-10, 10, 0)], orc.material(2, (0.9, 0.1, 0.1), 100.0))
+    b = orc.plane([(-10, -10, 4), (10, -10, 4), (10, 10, 4), (-10, 10, 4)], orc.material(2, (0.2, 0.4, 0.6), 100.0))
+    sc = orc.OracleScene([a, b])
+    cam = sc.camera((0, 0, 0), 30.0, 0.01, 1, 1)
+    cam.origin[:] = (0, 0, 2)          # between the mirrors; the one pixel looks along (-0.5, 0.5, -1) at mirror a
+    for depth, expect in ((1, (0.2, 0.4, 0.6)), (2, (0.9, 0.1, 0.1)), (0, (0.9, 0.1, 0.1))):
+        st = orc.settings(epsilon=1e-15, lighting=0, max_recursion_depth=depth)
+        rgb = sc.render(cam, st, n_threads=1)["rgb"][0, 0]
+        assert np.allclose(rgb, expect, atol=1e-7), (depth, rgb)

@@ -66,3 +66,105 @@ def test_camera_setup(orc):
         np.testing.assert_array_equal(np.array(cam.origin[:], dtype=np.float32).view(np.uint32), np.array(origin, dtype=np.float32).view(np.uint32))
         assert f32(cam.viewport_w) == vw and f32(cam.viewport_h) == vh
     s.close()
+
+
+def _unit(rs):
+    d = rs.standard_normal(3).astype(np.float32)
+    return np.array(npr.vnormalize(npr.vnormalize(list(d))), dtype=np.float32)   # RenderThread + Ray ctor
+
+
+def test_sphere_random(orc):
+    rs = np.random.RandomState(21)
+    hits = bounds = 0
+    out = np.zeros(7, dtype=np.float32)
+    for it in range(600):
+        c = rs.uniform(-3, 3, 3).astype(np.float32)
+        radius = f32(rs.uniform(0.2, 3.0))
+        o = rs.uniform(-6, 6, 3).astype(np.float32)
+        if it % 3 == 0:   # aim at the sphere so that most rays hit; every tenth ray starts on the surface
+            target = c + rs.uniform(-1, 1, 3).astype(np.float32) * radius
+            d = np.array(npr.vnormalize(npr.vnormalize(list((target - o).astype(np.float32)))), dtype=np.float32)
+        else:
+            d = _unit(rs)
+        if it % 10 == 0:
+            o = (c + radius * _unit(rs)).astype(np.float32)
+        eps = f32(1e-3) if it % 2 else f32(1e-15)
+        b_ref = npr.bounding_sphere_intersects(list(o), list(d), list(c), radius, eps)
+        b_got = orc.lib().orc_sphere_intersection(orc.P(o), orc.P(d), orc.P(c), radius, eps, 1, orc.P(out))
+        assert bool(b_got) == b_ref
+        bounds += b_ref
+        ref = npr.sphere_intersection(list(o), list(d), list(c), radius, eps)
+        got = orc.lib().orc_sphere_intersection(orc.P(o), orc.P(d), orc.P(c), radius, eps, 0, orc.P(out))
+        assert bool(got) == (ref is not None)
+        if ref is not None:
+            hits += 1
+            exp = np.array(list(ref[0]) + list(ref[1]) + [ref[2]], dtype=np.float32)
+            assert out.tobytes() == exp.tobytes()
+    assert hits > 100 and bounds > 100
+
+
+def test_plane_random(orc):
+    rs = np.random.RandomState(22)
+    hits = 0
+    out = np.zeros(7, dtype=np.float32)
+    for it in range(600):
+        n_c = 3 if it % 4 == 0 else 4
+        if it % 2 == 0:   # axis-aligned quads as in the Cornell box, else general corners
+            y = f32(rs.uniform(-2, 2))
+            x0, x1, z0, z1 = rs.uniform(-3, 0), rs.uniform(0, 3), rs.uniform(-3, 0), rs.uniform(0, 3)
+            corners = np.array([[x1, y, z0], [x0, y, z0], [x0, y, z1], [x1, y, z1]], dtype=np.float32)[:n_c]
+            corners = corners[:, rs.permutation(3)] if it % 6 == 0 else corners
+        else:
+            corners = rs.uniform(-3, 3, (n_c, 3)).astype(np.float32)
+        o = rs.uniform(-5, 5, 3).astype(np.float32)
+        target = corners.mean(axis=0) + rs.uniform(-1.5, 1.5, 3).astype(np.float32)
+        d = np.array(npr.vnormalize(npr.vnormalize(list((target - o).astype(np.float32)))), dtype=np.float32)
+        eps = f32(1e-3) if it % 3 else f32(1e-15)
+        ref = npr.plane_intersection(list(o), list(d), [list(r) for r in corners], eps)
+        flat = np.ascontiguousarray(corners.reshape(-1))
+        got = orc.lib().orc_plane_intersection(orc.P(o), orc.P(d), orc.P(flat), n_c, eps, orc.P(out))
+        assert got in (0, 1)
+        assert bool(got) == (ref is not None)
+        if ref is not None:
+            hits += 1
+            exp = np.array(list(ref[0]) + list(ref[1]) + [ref[2]], dtype=np.float32)
+            assert out.tobytes() == exp.tobytes()
+    assert hits > 100
+
+
+def test_refraction_direction_random(orc):
+    rs = np.random.RandomState(23)
+    out = np.zeros(3, dtype=np.float32)
+    tir = 0
+    for it in range(500):
+        n = _unit(rs)
+        d = _unit(rs)
+        index = f32([1.52, 1.31, 1.33, 2.417][it % 4])
+        ref = npr.refraction_direction(list(n), list(d), index)
+        orc.lib().orc_refraction_direction(orc.P(n), orc.P(d), index, orc.P(out))
+        assert out.tobytes() == np.array(ref, dtype=np.float32).tobytes()
+        refl = np.array(npr.reflection_direction([f32(-x) for x in n] if npr.vdot(list(n), list(d)) > 0 else list(n), list(d)), dtype=np.float32)
+        tir += int(out.tobytes() == refl.tobytes())
+    assert tir > 20   # total internal reflection was exercised
+
+
+def test_checkerboard_random(orc):
+    rs = np.random.RandomState(24)
+    out = np.zeros(3, dtype=np.float32)
+    seen = set()
+    for it in range(500):
+        lo = rs.uniform(-50, 0, 3).astype(np.float32)
+        hi = (lo + rs.uniform(0, 120, 3)).astype(np.float32)
+        if it % 5 == 0:
+            hi[1] = lo[1]   # a flat floor
+        mm = np.concatenate([lo, hi])
+        p = (lo + rs.uniform(-0.05, 1.05, 3).astype(np.float32) * (hi - lo)).astype(np.float32)
+        if it % 5 == 0:
+            p[1] = lo[1]
+        cell = rs.choice([1.0, 10.0, 2.5], 3).astype(np.float32)
+        ext = orc.material_ext(0.0, (1, 1, 0), (1, 0, 0), tuple(cell))
+        orc.lib().orc_checker_color(orc.P(mm), orc.P(p), C.byref(ext), orc.P(out))
+        ref = npr.checker_color(list(mm), list(p), (1, 1, 0), (1, 0, 0), list(cell))
+        assert out.tobytes() == np.array(ref, dtype=np.float32).tobytes()
+        seen.add(tuple(out))
+    assert seen == {(1.0, 1.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.0, 0.0)}
