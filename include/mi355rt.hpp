@@ -74,6 +74,7 @@ class ColorInformation {
    virtual ~ColorInformation() = default;
    virtual uint32_t kind() const { return MI355RT_MAT_COLOR; }
    virtual int32_t brdfId() const { return 0; }
+   virtual mi355rt_material_ext abiExt() const { return mi355rt_material_ext {}; }
    mi355rt_material abi() const
    {
       mi355rt_material m {};
@@ -121,17 +122,102 @@ class ReflectionMaterial : public ColorInformation {
    uint32_t kind() const override { return MI355RT_MAT_REFLECTION; }
 };
 
+// materials/RefractionMaterial.java:11-59
+class RefractionMaterial : public ColorInformation {
+ public:
+   static constexpr float INDEX_OF_AIR = 1.00029f, INDEX_OF_GLASS = 1.52f, INDEX_OF_ICE = 1.31f, INDEX_OF_WATER = 1.33f,
+                          INDEX_OF_QUARTZ = 1.46f, INDEX_OF_SAPPHIRE = 1.77f, INDEX_OF_DIAMOND = 2.417f;
+   float refractionIndex;
+   RefractionMaterial(Color3 d, float index) : ColorInformation(d, 100.0f), refractionIndex(index) {}
+   uint32_t kind() const override { return MI355RT_MAT_REFRACTION; }
+   mi355rt_material_ext abiExt() const override
+   {
+      mi355rt_material_ext e {};
+      e.refraction_index = refractionIndex;
+      return e;
+   }
+};
+
+// materials/CheckerboardMaterial.java:8-49: ColorInformation() (black, shininess 20) with two cell colours
+class CheckerboardMaterial : public ColorInformation {
+ public:
+   Color3 color1, color2;
+   float cellWidth, cellHeight, cellDepth;
+   CheckerboardMaterial(Color3 c1, Color3 c2, float w, float h, float d)
+      : ColorInformation(Color3 { 0.f, 0.f, 0.f }), color1(c1), color2(c2), cellWidth(w), cellHeight(h), cellDepth(d)
+   {
+   }
+   uint32_t kind() const override { return MI355RT_MAT_CHECKERBOARD; }
+   mi355rt_material_ext abiExt() const override
+   {
+      mi355rt_material_ext e {};
+      for (int c = 0; c < 3; c++) {
+         e.checker_color1[c] = color1[c];
+         e.checker_color2[c] = color2[c];
+      }
+      e.checker_cell[0] = cellWidth;
+      e.checker_cell[1] = cellHeight;
+      e.checker_cell[2] = cellDepth;
+      return e;
+   }
+};
+
+// bounds/BoundingVolume.java: what Scene.objects holds.  Here it is the description handed to the library, which
+// builds the KDTree / BoundingSphere / AxisAlignedBoundingBox behind it.
+class BoundingVolume {
+ public:
+   mi355rt_material material;
+   mi355rt_material_ext materialExt;
+   bool computeKDTree = true;
+   virtual ~BoundingVolume() = default;
+   virtual void fill(mi355rt_object_desc &d) const = 0;
+   const BoundingVolume *getBoundingVolume() const { return this; }
+
+ protected:
+   explicit BoundingVolume(const ColorInformation &colorInfo) : material(colorInfo.abi()), materialExt(colorInfo.abiExt()) {}
+};
+
+// sceneObjects/Sphere.java:15-22
+class Sphere : public BoundingVolume {
+ public:
+   float radius;
+   Color3 origin;
+   Sphere(float r, Color3 o, const ColorInformation &colorInfo) : BoundingVolume(colorInfo), radius(r), origin(o) {}
+   void fill(mi355rt_object_desc &d) const override
+   {
+      d.kind = MI355RT_OBJ_SPHERE;
+      for (int c = 0; c < 3; c++) d.center[c] = origin[c];
+      d.radius = radius;
+   }
+};
+
+// sceneObjects/Plane.java:28-76: three or four corners
+class Plane : public BoundingVolume {
+ public:
+   std::vector<Color3> corners;
+   Plane(std::vector<Color3> c, const ColorInformation &colorInfo) : BoundingVolume(colorInfo), corners(std::move(c))
+   {
+      if (corners.size() < 3) throw std::invalid_argument("The array of corner values must contain three or more vertices");   // Plane.java:33-35
+      if (corners.size() > 4) corners.resize(4);
+   }
+   void fill(mi355rt_object_desc &d) const override
+   {
+      d.kind = MI355RT_OBJ_PLANE;
+      d.n_corners = (uint32_t) corners.size();
+      for (size_t i = 0; i < corners.size(); i++)
+         for (int c = 0; c < 3; c++) d.corners[3 * i + c] = corners[i][c];
+   }
+};
+
 // sceneObjects/TriangleMesh.java:23-94: a PLY path (parsed with the reference loader's rules) or arrays
-class TriangleMesh {
+class TriangleMesh : public BoundingVolume {
  public:
    std::vector<float> vertices, normals;   // normals empty: synthesised as TriangleMesh.computeNormals
    std::vector<int32_t> indices;
-   mi355rt_material material;
-   bool computeKDTree;
 
-   TriangleMesh(const std::string &modelLocation, const ColorInformation &colorInfo, bool kdtree = true)
-      : material(colorInfo.abi()), computeKDTree(kdtree)
+   TriangleMesh(const std::string &modelLocation, const ColorInformation &colorInfo, bool kdtree = true) : BoundingVolume(colorInfo)
    {
+      computeKDTree = kdtree;
       uint32_t nv = 0, nf = 0;
       float *v = nullptr, *n = nullptr;
       int32_t *i = nullptr, has_normals = 0;
@@ -145,10 +231,19 @@ class TriangleMesh {
    }
    TriangleMesh(std::vector<float> v, std::vector<int32_t> i, const ColorInformation &colorInfo, bool kdtree = true,
                 std::vector<float> n = {})
-      : vertices(std::move(v)), normals(std::move(n)), indices(std::move(i)), material(colorInfo.abi()), computeKDTree(kdtree)
+      : BoundingVolume(colorInfo), vertices(std::move(v)), normals(std::move(n)), indices(std::move(i))
    {
+      computeKDTree = kdtree;
    }
-   const TriangleMesh *getBoundingVolume() const { return this; }   // the KDTree built inside the library
+   void fill(mi355rt_object_desc &d) const override
+   {
+      d.kind = MI355RT_OBJ_MESH;
+      d.mesh.vertices = vertices.data();
+      d.mesh.normals = normals.empty() ? nullptr : normals.data();
+      d.mesh.indices = indices.data();
+      d.mesh.n_vertices = (uint32_t) (vertices.size() / 3);
+      d.mesh.n_faces = (uint32_t) (indices.size() / 3);
+   }
 };
 
 // lighting/LightingModel.java:13-15, lighting/PhongLightingModel.java:18-54
@@ -159,38 +254,35 @@ class LightingModel {
 };
 class PhongLightingModel : public LightingModel {
  public:
-   PhongLightingModel(const Light &, const std::vector<const TriangleMesh *> &) {}
+   PhongLightingModel(const Light &, const std::vector<const BoundingVolume *> &) {}
    int kind() const override { return MI355RT_LIGHTING_PHONG; }
 };
 
 // Scene.java:14-38
 class Scene {
  public:
-   std::vector<const TriangleMesh *> objects;
+   std::vector<const BoundingVolume *> objects;
    Light light;
    std::array<float, 3> cameraOrientation;
    int lightingModel;
    float fov;
 
-   Scene(std::vector<const TriangleMesh *> objs, const Light &l, std::array<float, 3> orientation, const LightingModel &model, float fieldOfView,
+   Scene(std::vector<const BoundingVolume *> objs, const Light &l, std::array<float, 3> orientation, const LightingModel &model, float fieldOfView,
          int device = -1)
       : objects(std::move(objs)), light(l), cameraOrientation(orientation), lightingModel(model.kind()), fov(fieldOfView)
    {
-      std::vector<mi355rt_mesh_desc> descs(objects.size());
+      std::vector<mi355rt_object_desc> descs(objects.size(), mi355rt_object_desc {});
       bool kd = true, brdf = false;
-      for (size_t k = 0; k < objects.size(); k++) {
-         const TriangleMesh &m = *objects[k];
-         descs[k].vertices = m.vertices.data();
-         descs[k].normals = m.normals.empty() ? nullptr : m.normals.data();
-         descs[k].indices = m.indices.data();
-         descs[k].n_vertices = (uint32_t) (m.vertices.size() / 3);
-         descs[k].n_faces = (uint32_t) (m.indices.size() / 3);
-         descs[k].material = m.material;
+      for (size_t k = 0; k < objects.size(); k++) {   // TriangleMesh, Sphere or Plane, in Scene.objects order
+         const BoundingVolume &m = *objects[k];
+         m.fill(descs[k]);
+         descs[k].mesh.material = m.material;
+         descs[k].ext = m.materialExt;
          kd = kd && m.computeKDTree;
          brdf = brdf || m.material.kind == MI355RT_MAT_BRDF;
       }
       mi355rt_build_opts opts { RTStatics::MAX_DEPTH, RTStatics::MAX_CHILDREN, kd ? 1 : 0, device };
-      check(mi355rt_scene_create(descs.data(), (uint32_t) descs.size(), &opts, &handle_));
+      check(mi355rt_scene_create_objects(descs.data(), (uint32_t) descs.size(), &opts, &handle_));
       if (brdf) {
          const BRDFMaterial::Tables &t = BRDFMaterial::tables();
          if (t.n_dirs == 0) throw std::invalid_argument("BRDFMaterial::setTables must be called before building a BRDF scene");

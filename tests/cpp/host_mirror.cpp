@@ -24,6 +24,20 @@ static int run_abi()
       std::printf("material defaults wrong\n");
       return 1;
    }
+   RefractionMaterial glass({ 0.5f, 0.5f, 0.5f }, RefractionMaterial::INDEX_OF_GLASS);
+   CheckerboardMaterial checker({ 1.f, 1.f, 0.f }, { 1.f, 0.f, 0.f }, 10.f, 10.f, 10.f);
+   if (glass.abi().kind != MI355RT_MAT_REFRACTION || glass.abi().shininess != 100.0f || glass.abiExt().refraction_index != 1.52f ||
+       checker.abi().kind != MI355RT_MAT_CHECKERBOARD || checker.abi().diffuse[0] != 0.0f || checker.abi().shininess != 20.0f ||
+       checker.abiExt().checker_cell[2] != 10.f || checker.abiExt().checker_color1[1] != 1.f) {
+      std::printf("refraction / checkerboard defaults wrong\n");
+      return 1;
+   }
+   try {
+      Plane two({ { 0.f, 0.f, 0.f }, { 1.f, 0.f, 0.f } }, white);
+      std::printf("no error for a two-corner plane\n");
+      return 1;
+   } catch (const std::invalid_argument &) {
+   }
    try {
       TriangleMesh missing("/nonexistent/mesh.ply", white, true);
       std::printf("no error for a missing file\n");
@@ -52,6 +66,42 @@ static int run_abi()
    return 0;
 }
 
+static int write_frame(const Camera &camera, int W, int H, const char *path)
+{
+   FILE *f = std::fopen(path, "wb");
+   if (!f) return 1;
+   const float header[8] = { camera.cam.origin[0], camera.cam.origin[1], camera.cam.origin[2], camera.cam.viewport_w, camera.cam.viewport_h,
+                             RTStatics::EPSILON(), (float) W, (float) H };
+   std::fwrite(header, sizeof(float), 8, f);
+   std::fwrite(camera.rowMajorPixels().data(), sizeof(float), (size_t) 3 * W * H, f);
+   std::fwrite(camera.hitId.data(), sizeof(int32_t), (size_t) W * H, f);
+   std::fwrite(camera.hitW.data(), sizeof(float), (size_t) W * H, f);
+   std::fclose(f);
+   std::printf("RENDER_OK %dx%d pixel(0,0)=%g\n", W, H, camera.getPixel(0, 0)[0]);
+   return 0;
+}
+
+// Scenes.WHITTED_SCENE as RayTracer.getScene / getWhittedObjects(false) build it (RayTracer.java:111-113,155-167)
+static int run_whitted(char **argv)
+{
+   const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), ms = std::atoi(argv[4]);
+   const unsigned long long seed = std::strtoull(argv[5], nullptr, 10);
+   Light light({ 0.f, 100.f, 100.f }, { 0.3f, 0.3f, 0.3f }, { 0.5f, 0.5f, 0.9f });
+   Plane plane({ { -50.f, 0.f, -100.f }, { -50.f, -40.f, 25.f }, { 50.f, -40.f, 25.f }, { 50.f, 0.f, -100.f } },
+               CheckerboardMaterial({ 1.f, 1.f, 0.f }, { 1.f, 0.f, 0.f }, 10.f, 10.f, 10.f));
+   ReflectionMaterial blue({ 0.f, 0.f, 1.f });
+   RefractionMaterial glass({ 128 / 255.f, 128 / 255.f, 128 / 255.f }, RefractionMaterial::INDEX_OF_GLASS);
+   Sphere sphere1(5.f, { 0.f, -12.f, 0.f }, glass);
+   Sphere sphere2(3.f, { 5.f, -15.f, -10.f }, blue);
+   std::vector<const BoundingVolume *> volumes { plane.getBoundingVolume(), sphere1.getBoundingVolume(), sphere2.getBoundingVolume() };
+   PhongLightingModel model(light, volumes);
+   Scene scene(volumes, light, { 0.f, 0.f, 0.f }, model, 35.0f);
+   Camera camera(scene, ms, 1, RTStatics::NEAR_PLANE, W, H);
+   camera.rngSeed = seed;
+   camera.createImage();
+   return write_frame(camera, W, H, argv[6]);
+}
+
 static int run_render(char **argv)
 {
    const std::string ply = argv[2];
@@ -71,17 +121,7 @@ static int run_render(char **argv)
       std::printf("listener fired %d times\n", fired);
       return 1;
    }
-   FILE *f = std::fopen(argv[8], "wb");
-   if (!f) return 1;
-   const float header[8] = { camera.cam.origin[0], camera.cam.origin[1], camera.cam.origin[2], camera.cam.viewport_w, camera.cam.viewport_h,
-                             RTStatics::EPSILON(), (float) W, (float) H };
-   std::fwrite(header, sizeof(float), 8, f);
-   std::fwrite(camera.rowMajorPixels().data(), sizeof(float), (size_t) 3 * W * H, f);
-   std::fwrite(camera.hitId.data(), sizeof(int32_t), (size_t) W * H, f);
-   std::fwrite(camera.hitW.data(), sizeof(float), (size_t) W * H, f);
-   std::fclose(f);
-   std::printf("RENDER_OK %dx%d pixel(0,0)=%g\n", W, H, camera.getPixel(0, 0)[0]);
-   return 0;
+   return write_frame(camera, W, H, argv[8]);
 }
 
 int main(int argc, char **argv)
@@ -89,10 +129,11 @@ int main(int argc, char **argv)
    try {
       if (argc >= 2 && std::strcmp(argv[1], "abi") == 0) return run_abi();
       if (argc >= 9 && std::strcmp(argv[1], "render") == 0) return run_render(argv);
+      if (argc >= 7 && std::strcmp(argv[1], "whitted") == 0) return run_whitted(argv);
    } catch (const std::exception &e) {
       std::printf("exception: %s\n", e.what());
       return 2;
    }
-   std::printf("usage: host_mirror abi | render <ply> <W> <H> <ms> <seed> <fov> <out.bin>\n");
+   std::printf("usage: host_mirror abi | render <ply> <W> <H> <ms> <seed> <fov> <out.bin> | whitted <W> <H> <ms> <seed> <out.bin>\n");
    return 64;
 }

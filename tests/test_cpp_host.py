@@ -51,3 +51,33 @@ def test_cpp_mirror_frame_matches_oracle(rt, orc, tmp_path):
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     assert (hid >= 0).mean() > 0.1
     osc.close()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_whitted_scene_matches_oracle(orc, tmp_path):
+    """Plane / Sphere / CheckerboardMaterial / RefractionMaterial / ReflectionMaterial built in C++ the way
+    RayTracer.getWhittedObjects does (RayTracer.java:155-167), against the oracle."""
+    from helpers import compare_frames
+    W, H, ms, seed = 240, 180, 2, 5
+    out = str(tmp_path / "whitted.bin")
+    r = _run("whitted", W, H, ms, seed, out)
+    assert r.returncode == 0 and "RENDER_OK" in r.stdout, r.stdout
+    raw = np.fromfile(out, dtype=np.float32)
+    header, body = raw[:8], raw[8:]
+    rgb = body[: 3 * W * H].reshape(H, W, 3)
+    hid = body[3 * W * H: 4 * W * H].view(np.int32).reshape(H, W)
+    hw = body[4 * W * H: 5 * W * H].reshape(H, W)
+    floor = orc.plane([(-50, 0, -100), (-50, -40, 25), (50, -40, 25), (50, 0, -100)], orc.material(4, (0, 0, 0), 20.0),
+                      orc.material_ext(0, (1, 1, 0), (1, 0, 0), (10, 10, 10)))
+    glass = orc.sphere((0, -12, 0), 5, orc.material(3, (128 / 255.0,) * 3, 100.0), orc.material_ext(1.52))
+    mirror = orc.sphere((5, -15, -10), 3, orc.material(2, (0, 0, 1), 100.0))
+    osc = orc.OracleScene([floor, glass, mirror])
+    ocam = osc.camera((0, 0, 0), 35.0, 0.01, W, H)
+    np.testing.assert_array_equal(np.array(ocam.origin[:], dtype=np.float32), header[:3])
+    assert np.float32(osc.epsilon()) == header[5] == np.float32(1e-3)
+    ost = orc.settings(epsilon=osc.epsilon(), ms=ms, lighting=1, seed=seed)
+    o = osc.render(ocam, ost, n_threads=8)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(rgb, hid, hw, o)
+    assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
+    assert set(np.unique(o["hit_obj"])) == {-1, 0, 1, 2}
+    osc.close()
