@@ -95,6 +95,7 @@ struct mi355rt_scene {
    DevObjectExt *d_ext = nullptr;   // parallel to d_objs: sphere / plane / refraction / checkerboard parameters
    int n_analytic = 0;              // spheres + planes
    bool has_refraction = false;
+   bool boxes_finite = true;        // see SceneArgs.boxes_finite
    void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;   // all objects, concatenated
    float *d_brdf_dirs = nullptr, *d_brdf_weights = nullptr;
    int32_t n_dirs = 0, n_materials = 0;
@@ -372,6 +373,7 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.sc.scene_abs_max = s->abs_max;
    p.sc.ext = s->d_ext;
    p.sc.n_analytic = s->n_analytic;
+   p.sc.boxes_finite = s->boxes_finite ? 1 : 0;
    p.max_recursion_depth = st->max_recursion_depth;
    std::memcpy(p.origin, cam->origin, sizeof(p.origin));
    std::memcpy(p.rot, cam->rotation, sizeof(p.rot));
@@ -572,7 +574,8 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
    std::vector<DevObjectExt> dev_ext(dev_objs.size());
    std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
    // all objects share one node array, one slot array and one normal array (links absolute)
-   std::vector<NodeRec> all_nodes;
+   std::vector<DevNodeRec> all_nodes;
+   bool boxes_finite = true;
    std::vector<float> all_tris, all_fnrm;
    size_t slot_total = 0, face_total = 0;
 
@@ -610,7 +613,22 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
          for (NodeRec rec : bo_out.nodes) {
             if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? slot_base : node_base);
             if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? slot_base : node_base);
-            all_nodes.push_back(rec);
+            DevNodeRec d;
+            const float *lo[2] = { rec.lmin, rec.rmin }, *hi[2] = { rec.lmax, rec.rmax };
+            for (int side = 0; side < 2; side++) {
+               d.lo_x[side] = lo[side][0];
+               d.lo_y[side] = lo[side][1];
+               d.lo_z[side] = lo[side][2];
+               d.hi_x[side] = hi[side][0];
+               d.hi_y[side] = hi[side][1];
+               d.hi_z[side] = hi[side][2];
+               for (int c = 0; c < 3; c++) boxes_finite = boxes_finite && std::isfinite(lo[side][c]) && std::isfinite(hi[side][c]);
+            }
+            d.llink = rec.llink;
+            d.rlink = rec.rlink;
+            d.lcnt = rec.lcnt;
+            d.rcnt = rec.rcnt;
+            all_nodes.push_back(d);
          }
          // leaf slots: 3 x float4 per (leaf, face): { v0, faceId } { v1, faces left in the leaf } { v2, 0 }
          all_tris.resize(12 * (slot_base + bo_out.slot_face.size()), 0.0f);
@@ -684,7 +702,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
    }
    {
       int rc;
-      if ((rc = upload(all_nodes.data(), all_nodes.size() * sizeof(NodeRec), &s->d_nodes, s)) ||
+      if ((rc = upload(all_nodes.data(), all_nodes.size() * sizeof(DevNodeRec), &s->d_nodes, s)) ||
           (rc = upload(all_tris.data(), all_tris.size() * sizeof(float), &s->d_tris, s)) ||
           (rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s))) {
          release_scene(s);
@@ -697,6 +715,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       if (std::isfinite(s->smax[c])) amax = std::fmax(amax, std::fabs(s->smax[c]));
    }
    s->abs_max = n_meshes ? amax : 0.f;
+   s->boxes_finite = boxes_finite;
    int rc;
    if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s)) ||
        (rc = upload(dev_ext.data(), sizeof(DevObjectExt) * dev_ext.size(), (void **) &s->d_ext, s))) {
@@ -1012,6 +1031,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    a.sc.scene_abs_max = scene->abs_max;
    a.sc.ext = scene->d_ext;
    a.sc.n_analytic = scene->n_analytic;
+   a.sc.boxes_finite = scene->boxes_finite ? 1 : 0;
    a.n = (uint32_t) n;
    a.band_cap = (uint32_t) ((n + N_BANDS - 1) / N_BANDS);
    a.origins = (const float *) buf.p[0];

@@ -62,6 +62,15 @@ __device__ __forceinline__ void make_ray(Ray &r, V3 o, V3 d)
    r.inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));   // operands of the packed-f32 instructions
+
+// every operand the slab test will see from this ray is finite (so none of its products can be a NaN)
+__device__ __forceinline__ bool plain_ray(const Ray &r)
+{
+   const float s = (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z)) + (fabsf(r.inv.x) + fabsf(r.inv.y) + fabsf(r.inv.z));
+   return s < __builtin_inff();   // false for any inf or NaN among them (a finite sum that overflows only costs the fast path)
+}
+
 // RTStatics.aabbIntersection (RTStatics.java:102-158) with 1/direction hoisted out (same value on
 // every call for one ray).  Branch-free: after a "return false" nothing else is observable, so
 // evaluating the rest is equivalent.  Every comparison is the reference's own, so NaNs fall

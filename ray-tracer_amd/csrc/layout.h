@@ -1,17 +1,20 @@
 // layout.h -- HBM data layout shared by the host side and the HIP kernels of libmi355rt.
 //
 // SCENE (read-only during a frame).  One mesh object (= one KDTree of the reference,
-// bounds/KDTree.java) is three arrays:
+// bounds/KDTree.java) is three arrays (NodeRec is the host builder's form, DevNodeRec what is uploaded):
 //
 // All objects' records are concatenated (links absolute); DevObject gives each object's root.
 //   nodes : one 64-byte record per INTERNAL node of the reference hierarchy, in DFS pre-order.
 //           A record carries the boxes and links of BOTH children, so one 4 x 128-bit fetch
 //           decides both child tests (the reference tests left.minMax / right.minMax at the
 //           parent, bounds/KDNode.java:97,101).
-//             float4 a = { lmin.x, lmin.y, lmin.z, lmax.x }
-//             float4 b = { lmax.y, lmax.z, rmin.x, rmin.y }
-//             float4 c = { rmin.z, rmax.x, rmax.y, rmax.z }
+//             float4 a = { lmin.x, rmin.x, lmin.y, rmin.y }
+//             float4 b = { lmin.z, rmin.z, lmax.x, rmax.x }
+//             float4 c = { lmax.y, rmax.y, lmax.z, rmax.z }
 //             int4   d = { llink, rlink, lcnt, rcnt }
+//           The two children's values of one coordinate sit side by side (an aligned register pair after the
+//           128-bit load), so the walker's slab arithmetic runs both children through packed-f32 instructions
+//           (v_pk_add_f32 / v_pk_mul_f32: two results per issue slot).
 //           link: cnt == 0 -> index of the child's node record; cnt > 0 -> first leaf slot of a
 //           leaf child holding cnt faces; link == LINK_NONE -> the reference's null child.
 //   tris  : one 48-byte slot per (leaf, face) pair, leaves in left-to-right DFS order, faces in
@@ -52,6 +55,13 @@ struct NodeRec {   // 64 B
 };
 static_assert(sizeof(NodeRec) == 64, "node record must be 64 bytes");
 
+// the same record as uploaded: left / right interleaved per coordinate ([0] left, [1] right)
+struct DevNodeRec {   // 64 B
+   float lo_x[2], lo_y[2], lo_z[2], hi_x[2], hi_y[2], hi_z[2];
+   int32_t llink, rlink, lcnt, rcnt;
+};
+static_assert(sizeof(DevNodeRec) == 64, "node record must be 64 bytes");
+
 struct DevMaterial {
    uint32_t kind;
    float diffuse[3], specular[3];
@@ -91,7 +101,7 @@ struct DevObject {
 // node links and leaf slots are absolute, so a wave's lanes may be inside different objects.
 struct SceneArgs {
    const DevObject *objs;
-   const void *nodes;   // NodeRec[]
+   const void *nodes;   // DevNodeRec[]
    const void *tris;    // float4[3 * (n_slots + 1)]
    const void *fnrm;    // float4[3 * n_faces]
    int32_t n_objs;
@@ -99,6 +109,7 @@ struct SceneArgs {
    float scene_abs_max;   // max |coordinate| of the scene bounds (prune margin)
    const DevObjectExt *ext;   // [n_objs]
    int32_t n_analytic;        // spheres + planes among the objects
+   int32_t boxes_finite;      // every node box is finite: rays with finite origin and 1/direction may take the packed slab test
 };
 
 // Every queue is N_BANDS sub-queues of band_cap slots each: the pass's 8x8 pixel groups are cut into

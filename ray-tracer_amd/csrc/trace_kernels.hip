@@ -401,8 +401,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    // role, owner, pending, k and mirror share one register (the kernel sits at the 80-VGPR step for 6 waves/SIMD)
    struct {
       unsigned role : 2, owner : 6, pending : 8;
-      int k : 8, mirror : 8;
+      int k : 7, mirror : 7;   // -1 .. MAX_OBJECTS - 1
+      unsigned plain : 1;      // finite origin and 1/direction (and finite node boxes): no NaN can arise in the slab test
    } st;
+   static_assert(MAX_OBJECTS <= 64, "k and mirror are 7-bit fields");
    st.role = ROLE_IDLE;
    st.owner = lane;      // the lane whose ray this lane is walking (itself unless ROLE_HELPER)
    st.pending = 0;       // ROLE_OWNER: helpers still walking parts of my current object
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    make_ray(r, mk3(0, 0, 0), mk3(0, 0, -1));
    st.mirror = -1;
    st.k = -1;
+   st.plain = 0;
    int cur = STACK_EMPTY;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                      st.mirror = -1;
                   }
                   make_ray(r, o, d);
+                  st.plain = plain_ray(r) && a.sc.boxes_finite;
                   st.role = ROLE_OWNER;
                   st.owner = lane;
                   st.pending = 0;
@@ -635,6 +639,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                r.o = mk3(ox, oy, oz);
                r.d = mk3(dx, dy, dz);
                r.inv = mk3(ix, iy, iz);
+               st.plain = plain_ray(r) && a.sc.boxes_finite;
                age = v_age;
                cur = entry;
                s = ~cur;
@@ -704,15 +709,37 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          }
          float tl = 0.0f, tr = 0.0f;
          bool lok = false, rok = false;
-         if (nd.x != LINK_NONE) {
-            if (STATS) n_box++;
-            lok = slab_test(r, nearp, farp, na.x, na.y, na.z, na.w, nb.x, nb.y, tl) &&
-                  !(origin_box_dist2(r, na.x, na.y, na.z, na.w, nb.x, nb.y) > lim2);
-         }
-         if (nd.y != LINK_NONE) {
-            if (STATS) n_box++;
-            rok = slab_test(r, nearp, farp, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w, tr) &&
-                  !(origin_box_dist2(r, nb.z, nb.w, nc.x, nc.y, nc.z, nc.w) > lim2);
+         if (STATS) n_box += (nd.x != LINK_NONE ? 1u : 0u) + (nd.y != LINK_NONE ? 1u : 0u);
+         if (st.plain) {
+            // Both children at once in packed f32 (the record interleaves them).  With every operand finite no NaN can
+            // arise, and RTStatics.aabbIntersection (RTStatics.java:102-158) reduces to its textbook form: per axis
+            // the reference's sign-selected (tmin, tmax) IS (min, max) of the two products (rounding is monotone and
+            // lo <= hi), its two early-outs and merges are "the three intervals intersect", and what it compares
+            // with FAR / NEAR are max3 of the tmins and min3 of the tmaxs -- the same values, the same answer.
+            const f2 ax = f2 { na.x, na.y } - r.o.x, ay = f2 { na.z, na.w } - r.o.y, az = f2 { nb.x, nb.y } - r.o.z;
+            const f2 bx = f2 { nb.z, nb.w } - r.o.x, by = f2 { nc.x, nc.y } - r.o.y, bz = f2 { nc.z, nc.w } - r.o.z;
+            const f2 t1x = ax * r.inv.x, t1y = ay * r.inv.y, t1z = az * r.inv.z;
+            const f2 t2x = bx * r.inv.x, t2y = by * r.inv.y, t2z = bz * r.inv.z;
+            // squared distance from the origin to each box (the prune test), from the same differences
+            const f2 ddx = { fmaxf(fmaxf(ax.x, -bx.x), 0.0f), fmaxf(fmaxf(ax.y, -bx.y), 0.0f) };
+            const f2 ddy = { fmaxf(fmaxf(ay.x, -by.x), 0.0f), fmaxf(fmaxf(ay.y, -by.y), 0.0f) };
+            const f2 ddz = { fmaxf(fmaxf(az.x, -bz.x), 0.0f), fmaxf(fmaxf(az.y, -bz.y), 0.0f) };
+            const f2 d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+            tl = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
+            tr = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
+            const float hl = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
+            const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
+            lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
+            rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
+         } else {
+            // a ray with a zero direction component (1/d infinite) or non-finite data: the reference's own branch
+            // structure, so that NaNs fall where they fall there
+            if (nd.x != LINK_NONE)
+               lok = slab_test(r, nearp, farp, na.x, na.z, nb.x, nb.z, nc.x, nc.z, tl) &&
+                     !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > lim2);
+            if (nd.y != LINK_NONE)
+               rok = slab_test(r, nearp, farp, na.y, na.w, nb.y, nb.w, nc.y, nc.w, tr) &&
+                     !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > lim2);
          }
          const int le = nd.z > 0 ? ~nd.x : nd.x;   // stack / cursor form of each child: leaf = ~first_slot
          const int re = nd.w > 0 ? ~nd.y : nd.y;
