@@ -403,6 +403,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       unsigned role : 2, owner : 6, pending : 8;
       int k : 7, mirror : 7;   // -1 .. MAX_OBJECTS - 1
       unsigned plain : 1;      // finite origin and 1/direction (and finite node boxes): no NaN can arise in the slab test
+      unsigned unsaved : 1;    // MODE_CLOSEST, ROLE_IDLE: the finished ray's result is still in registers (see "retire" below)
    } st;
    static_assert(MAX_OBJECTS <= 64, "k and mirror are 7-bit fields");
    st.role = ROLE_IDLE;
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    st.mirror = -1;
    st.k = -1;
    st.plain = 0;
+   st.unsaved = 0;
    int cur = STACK_EMPTY;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
@@ -497,10 +499,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   s = ~cur;
                }
             } else {
-               if (MODE == MODE_CLOSEST) {
+               if (MODE == MODE_CLOSEST) st.unsaved = 1;
+               else a.mat0[4 * (size_t) qi + 3] = occluded ? 1.0f : 0.0f;
+               st.role = ROLE_IDLE;
+            }
+         }
+
+         // ---- retire: the winner's point, barycentrics and normal are recomputed once (same arithmetic => same bits)
+         // and the hit record is written.  A ray finishes somewhere in the wave every other trip, and doing this for one
+         // lane at a time cost a fifth of the kernel's instructions.  A finished lane keeps its result in registers
+         // instead (nothing touches an idle lane's ray or best-so-far) until the wave is about to hand idle lanes new
+         // work -- a refill or a steal -- and then all of them are written in one go.
+         if (MODE == MODE_CLOSEST) {
+            const unsigned long long um = __ballot(st.unsaved != 0);
+            if (um != 0ull) {
+               const unsigned long long idle_now = __ballot(st.role == ROLE_IDLE);
+               const int n_idle = __popcll(idle_now);
+               const bool refill_now = !exhausted && (n_idle >= a.refill_min || idle_now == ~0ull);
+               const bool steal_now = exhausted || n_idle >= a.steal_min || a.age_min < (1 << 29);
+               if ((refill_now || steal_now) && st.unsaved) {
                   float4 h0 = make_float4(0, 0, 0, 0), h1 = make_float4(0, 0, 0, __int_as_float(-1));
                   if (best_obj >= 0) {
-                     // the winner's point, barycentrics and normal, recomputed once (same arithmetic => same bits)
                      const float4 *t = tris + 3 * (size_t) best_slot;
                      const float4 A = t[0], B = t[1], C = t[2];
                      float u = 0, v = 0, dist = 0;
@@ -519,10 +538,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   hq[0] = h0;
                   hq[1] = h1;
                   a.hit_obj[qi] = best_obj;
-               } else {
-                  a.mat0[4 * (size_t) qi + 3] = occluded ? 1.0f : 0.0f;
+                  st.unsaved = 0;
                }
-               st.role = ROLE_IDLE;
             }
          }
 
