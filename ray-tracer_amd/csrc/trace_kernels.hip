@@ -1272,7 +1272,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.cursor_index = cursor_index;
    a.band_cap = band_cap;
    a.stats = stats;
-   a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
+   a.refill_min = tunable("MI355RT_REFILL_MIN", 24);
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
@@ -1323,11 +1323,11 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.cursor_index = cursor_index;
    a.band_cap = p.band_cap;
    a.stats = p.stats;
-   a.refill_min = tunable("MI355RT_REFILL_MIN", 32);
-   a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
+   a.refill_min = tunable("MI355RT_REFILL_MIN_SHADOW", 64);   // shadow rays are short: a wave refills whole, and meanwhile helps its old rays (age_min)
+   a.steal_min = tunable("MI355RT_STEAL_MIN_SHADOW", 64);
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
-   a.age_min = tunable("MI355RT_AGE_MIN", 4);
+   a.age_min = tunable("MI355RT_AGE_MIN", 8);
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream);
