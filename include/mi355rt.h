@@ -159,7 +159,10 @@ typedef struct mi355rt_scene mi355rt_scene;
 
 /* Replaces `new KDTree(mesh, vertices, normals, indices, colorInfo, computeKDTree)` per mesh
  * (bounds/KDTree.java:24-56, bounds/KDNode.java:29-90) and `new Scene(volumes, ...)`'s bounds
- * (Scene.java:21-33): builds the reference's hierarchy, flattens it and uploads it to HBM. */
+ * (Scene.java:21-33): builds the reference's hierarchy, flattened, in HBM.  The hierarchy of a mesh whose root
+ * splits and whose vertices are all finite is built on the GPU, level by level; any other
+ * mesh, and every mesh when the environment has MI355RT_BUILDER=host, by the equivalent host builder.  Both give
+ * the same bytes. */
 int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts,
                          mi355rt_scene **out);
 /* The same for any mix of meshes, spheres and planes in Scene.objects order (RayTracer.getWhittedObjects /
@@ -257,6 +260,12 @@ int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_d
  * lifetimes; [16..24] per-walker rays / box tests / triangle tests; [25..42] per-walker timeline, [43..58] rays by trips taken
  * (trace_kernels.hip ST_*).  No counterpart in the reference. */
 int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[64]);
+
+/* Diagnostic: FNV-1a digests of the scene's three device arrays as uploaded -- out[0] node records, out[1] leaf
+ * slots, out[2] face normals -- and out[3] = 1 if any mesh's hierarchy was built on the GPU.  The tests use it to
+ * show that the GPU builder and the host builder (environment MI355RT_BUILDER=host) produce the same bytes.
+ * No counterpart in the reference. */
+int mi355rt_debug_scene_digest(mi355rt_scene *scene, uint64_t out[4]);
 
 const char *mi355rt_last_error(void);
 int mi355rt_abi_version(void);

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "mi355rt_trace_rays": (C.c_int, [C.c_void_p, C.POINTER(Settings), C.c_uint64, c_float_p, c_float_p, c_int32_p,
                                      c_int32_p, c_float_p, c_float_p, c_float_p]),
     "mi355rt_debug_arith": (C.c_int, [C.c_uint64, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p]),
+    "mi355rt_debug_scene_digest": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mi355rt_debug_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mi355rt_ply_load": (C.c_int, [C.c_char_p, c_uint32_p, c_uint32_p, C.POINTER(c_float_p), C.POINTER(c_float_p),
                                    C.POINTER(c_int32_p), c_int32_p]),

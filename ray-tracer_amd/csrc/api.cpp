@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -13,6 +15,7 @@
 
 #include "../../include/mi355rt.h"
 #include "host_math.hpp"
+#include "gpu_build.hpp"
 #include "kernels.h"
 #include "layout.h"
 #include "ply_reader.hpp"
@@ -96,6 +99,8 @@ struct mi355rt_scene {
    int n_analytic = 0;              // spheres + planes
    bool has_refraction = false;
    bool boxes_finite = true;        // see SceneArgs.boxes_finite
+   bool any_gpu_build = false;
+   size_t n_node_recs = 0, n_tri_floats = 0, n_fnrm_floats = 0;   // sizes of d_nodes / d_tris / d_fnrm
    void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;   // all objects, concatenated
    float *d_brdf_dirs = nullptr, *d_brdf_weights = nullptr;
    int32_t n_dirs = 0, n_materials = 0;
@@ -573,11 +578,24 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
    std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
    std::vector<DevObjectExt> dev_ext(dev_objs.size());
    std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
-   // all objects share one node array, one slot array and one normal array (links absolute)
-   std::vector<DevNodeRec> all_nodes;
+   // all objects share one node array, one slot array and one normal array (links absolute); each object's part is
+   // built on the host (scene_build.cpp) or on the GPU (gpu_build.hip) and copied to its place at the end
+   struct Part {
+      std::vector<DevNodeRec> nodes;   // host-built: records with absolute links
+      std::vector<float> tris;         // host-built: 12 floats per slot
+      GpuBuiltObject gpu;              // GPU-built: device buffers with relative links
+      bool on_gpu = false;
+      size_t node_base = 0, slot_base = 0, n_nodes = 0, n_slots = 0;
+   };
+   std::vector<Part> parts(n_meshes ? n_meshes : 1);
+   auto free_parts = [&parts]() {
+      for (Part &p : parts) gpu_build_free(p.gpu);
+   };
    bool boxes_finite = true;
-   std::vector<float> all_tris, all_fnrm;
-   size_t slot_total = 0, face_total = 0;
+   std::vector<float> all_fnrm;
+   size_t slot_total = 0, face_total = 0, node_total = 0;
+   const char *builder_env = getenv("MI355RT_BUILDER");   // "host": never build on the GPU (tuning / tests); default: GPU where it applies
+   const bool allow_gpu_build = !(builder_env && std::string(builder_env) == "host");
 
    try {
       for (uint32_t i = 0; i < n_meshes; i++) {
@@ -593,60 +611,106 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
          if (od.kind != MI355RT_OBJ_MESH) {
             const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
             if (!err.empty()) {
+               free_parts();
                release_scene(s);
                return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": " + err);
             }
             continue;
          }
+         Part &part = parts[i];
+         // The GPU builder takes every mesh whose root splits and whose vertices are all finite (Java's Math.min / max
+         // treat NaN specially; the host builder restates that, the GPU's integer-key min / max do not).
+         bool gpu_build = allow_gpu_build && bo.use_kdtree && bo.max_depth >= 1 && md.n_faces > (uint32_t) std::max(bo.max_children, 0) &&
+                          md.vertices && md.indices;
+         for (size_t v = 0; gpu_build && v < 3 * (size_t) md.n_vertices; v++) gpu_build = std::isfinite(md.vertices[v]);
+         BuildOptions bo_obj = bo;
+         bo_obj.build_tree = !gpu_build;
          BuiltObject bo_out;
-         const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo, bo_out);
+         const auto t_prep = std::chrono::steady_clock::now();
+         const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo_obj, bo_out);
          if (!err.empty()) {
+            free_parts();
             release_scene(s);
             return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
          }
-         const size_t node_base = all_nodes.size(), slot_base = slot_total, face_base = face_total;
-         if (node_base + bo_out.nodes.size() > (size_t) 0x7ffffff0 || slot_base + bo_out.slot_face.size() > (size_t) 0x7ffffff0 ||
+         const size_t node_base = node_total, slot_base = slot_total, face_base = face_total;
+         uint64_t n_leaves = bo_out.n_leaves;
+         int32_t tree_depth = bo_out.max_depth;
+         const auto t_tree = std::chrono::steady_clock::now();
+         if (gpu_build) {
+            std::string gerr;
+            const hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj, part.gpu, gerr);
+            if (ge != hipSuccess) {
+               free_parts();
+               release_scene(s);
+               if (!gerr.empty()) return fail(MI355RT_E_LIMIT, "mesh " + std::to_string(i) + ": " + gerr);
+               return hip_fail(ge, "GPU hierarchy build");
+            }
+            part.on_gpu = true;
+            s->any_gpu_build = true;
+            part.n_nodes = (size_t) part.gpu.n_nodes;
+            part.n_slots = (size_t) part.gpu.n_slots;
+            n_leaves = part.gpu.n_leaves;
+            tree_depth = part.gpu.max_depth;
+         } else {
+            part.n_nodes = bo_out.nodes.size();
+            part.n_slots = bo_out.slot_face.size();
+         }
+         part.node_base = node_base;
+         part.slot_base = slot_base;
+         if (node_base + part.n_nodes > (size_t) 0x7ffffff0 || slot_base + part.n_slots > (size_t) 0x7ffffff0 ||
              face_base + md.n_faces > (size_t) 0x7ffffff0) {
+            free_parts();
             release_scene(s);
             return fail(MI355RT_E_LIMIT, "scene exceeds 2^31 nodes, leaf slots or faces");
          }
-         for (NodeRec rec : bo_out.nodes) {
-            if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? slot_base : node_base);
-            if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? slot_base : node_base);
-            DevNodeRec d;
-            const float *lo[2] = { rec.lmin, rec.rmin }, *hi[2] = { rec.lmax, rec.rmax };
-            for (int side = 0; side < 2; side++) {
-               d.lo_x[side] = lo[side][0];
-               d.lo_y[side] = lo[side][1];
-               d.lo_z[side] = lo[side][2];
-               d.hi_x[side] = hi[side][0];
-               d.hi_y[side] = hi[side][1];
-               d.hi_z[side] = hi[side][2];
-               for (int c = 0; c < 3; c++) boxes_finite = boxes_finite && std::isfinite(lo[side][c]) && std::isfinite(hi[side][c]);
+         if (!gpu_build) {
+            part.nodes.reserve(bo_out.nodes.size());
+            for (NodeRec rec : bo_out.nodes) {
+               if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? slot_base : node_base);
+               if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? slot_base : node_base);
+               DevNodeRec d;
+               const float *lo[2] = { rec.lmin, rec.rmin }, *hi[2] = { rec.lmax, rec.rmax };
+               for (int side = 0; side < 2; side++) {
+                  d.lo_x[side] = lo[side][0];
+                  d.lo_y[side] = lo[side][1];
+                  d.lo_z[side] = lo[side][2];
+                  d.hi_x[side] = hi[side][0];
+                  d.hi_y[side] = hi[side][1];
+                  d.hi_z[side] = hi[side][2];
+                  for (int c = 0; c < 3; c++) boxes_finite = boxes_finite && std::isfinite(lo[side][c]) && std::isfinite(hi[side][c]);
+               }
+               d.llink = rec.llink;
+               d.rlink = rec.rlink;
+               d.lcnt = rec.lcnt;
+               d.rcnt = rec.rcnt;
+               part.nodes.push_back(d);
             }
-            d.llink = rec.llink;
-            d.rlink = rec.rlink;
-            d.lcnt = rec.lcnt;
-            d.rcnt = rec.rcnt;
-            all_nodes.push_back(d);
-         }
-         // leaf slots: 3 x float4 per (leaf, face): { v0, faceId } { v1, faces left in the leaf } { v2, 0 }
-         all_tris.resize(12 * (slot_base + bo_out.slot_face.size()), 0.0f);
-         for (size_t sidx = 0; sidx < bo_out.slot_face.size(); sidx++) {
-            const int32_t f = bo_out.slot_face[sidx];
-            float *dst = all_tris.data() + 12 * (slot_base + sidx);
-            for (int kx = 0; kx < 3; kx++) {
-               const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
-               dst[4 * kx + 0] = v[0];
-               dst[4 * kx + 1] = v[1];
-               dst[4 * kx + 2] = v[2];
-               dst[4 * kx + 3] = 0.0f;
+            // leaf slots: 3 x float4 per (leaf, face): { v0, faceId } { v1, faces left in the leaf } { v2, 0 }
+            part.tris.assign(12 * bo_out.slot_face.size(), 0.0f);
+            for (size_t sidx = 0; sidx < bo_out.slot_face.size(); sidx++) {
+               const int32_t f = bo_out.slot_face[sidx];
+               float *dst = part.tris.data() + 12 * sidx;
+               for (int kx = 0; kx < 3; kx++) {
+                  const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
+                  dst[4 * kx + 0] = v[0];
+                  dst[4 * kx + 1] = v[1];
+                  dst[4 * kx + 2] = v[2];
+                  dst[4 * kx + 3] = 0.0f;
+               }
+               std::memcpy(&dst[3], &f, sizeof(float));
+               const int32_t remaining = bo_out.slot_remaining[sidx];
+               std::memcpy(&dst[7], &remaining, sizeof(float));
             }
-            std::memcpy(&dst[3], &f, sizeof(float));
-            const int32_t remaining = bo_out.slot_remaining[sidx];
-            std::memcpy(&dst[7], &remaining, sizeof(float));
          }
-         slot_total += bo_out.slot_face.size();
+         node_total += part.n_nodes;
+         slot_total += part.n_slots;
+         if (getenv("MI355RT_BUILD_TIMING")) {   // profiling aid
+            const auto t_end = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + normals + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
+                         gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
+                         gpu_build ? "GPU hierarchy" : "records", std::chrono::duration<double>(t_end - t_tree).count());
+         }
          all_fnrm.resize(12 * (face_base + md.n_faces), 0.0f);
          for (size_t f = 0; f < md.n_faces; f++) {
             float *dst = all_fnrm.data() + 12 * (face_base + f);
@@ -670,16 +734,16 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
          std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
          std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
          ho.shadow_distance = bo_out.shadow_distance;
-         ho.n_nodes = bo_out.nodes.size();
-         ho.n_leaves = bo_out.n_leaves;
-         ho.n_slots = bo_out.slot_face.size();
-         ho.max_depth = bo_out.max_depth;
+         ho.n_nodes = part.n_nodes;
+         ho.n_leaves = n_leaves;
+         ho.n_slots = part.n_slots;
+         ho.max_depth = tree_depth;
          ho.is_mesh = true;
          DevObject &d = dev_objs[i];
          d.kind = OBJ_MESH;
          std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
          std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
-         d.root_entry = !bo_out.root_is_leaf ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
+         d.root_entry = (gpu_build || !bo_out.root_is_leaf) ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
          d.shadow_distance = bo_out.shadow_distance;
          d.face_base = (int32_t) face_base;
          d.node_base = (int32_t) node_base;
@@ -692,19 +756,46 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
          }
       }
-      // padding slots: a walker reads a few slots past the end of a leaf
-      all_tris.resize(12 * (slot_total + LEAF_PAD_SLOTS), 0.0f);
-      const int32_t one = 1;
-      for (int q = 0; q < LEAF_PAD_SLOTS; q++) std::memcpy(&all_tris[12 * (slot_total + q) + 7], &one, sizeof(float));
    } catch (const std::bad_alloc &) {
+      free_parts();
       release_scene(s);
       return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
    }
    {
+      // the shared arrays; LEAF_PAD_SLOTS zero slots (one face left) follow the last leaf: a walker reads a few slots past a leaf's end
+      const size_t node_bytes = std::max<size_t>(node_total, 1) * sizeof(DevNodeRec);
+      const size_t tri_floats = 12 * (slot_total + LEAF_PAD_SLOTS);
+      hipError_t e = hipMalloc(&s->d_nodes, node_bytes);
+      if (e == hipSuccess) e = hipMalloc(&s->d_tris, tri_floats * sizeof(float));
+      if (e == hipSuccess) {
+         s->device_bytes += node_bytes + tri_floats * sizeof(float);
+         std::vector<float> pad(12 * (size_t) LEAF_PAD_SLOTS, 0.0f);
+         const int32_t one = 1;
+         for (int q = 0; q < LEAF_PAD_SLOTS; q++) std::memcpy(&pad[12 * (size_t) q + 7], &one, sizeof(float));
+         e = hipMemcpy((float *) s->d_tris + 12 * slot_total, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice);
+      }
+      for (Part &part : parts) {
+         if (e != hipSuccess) break;
+         if (part.on_gpu) {
+            e = gpu_build_relocate(part.gpu, (DevNodeRec *) s->d_nodes, (float *) s->d_tris, (int32_t) part.node_base, (int32_t) part.slot_base);
+         } else {
+            if (!part.nodes.empty())
+               e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, part.nodes.data(), part.nodes.size() * sizeof(DevNodeRec), hipMemcpyHostToDevice);
+            if (e == hipSuccess && !part.tris.empty())
+               e = hipMemcpy((float *) s->d_tris + 12 * part.slot_base, part.tris.data(), part.tris.size() * sizeof(float), hipMemcpyHostToDevice);
+         }
+      }
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      free_parts();
+      if (e != hipSuccess) {
+         release_scene(s);
+         return hip_fail(e, "hierarchy upload");
+      }
+      s->n_node_recs = node_total;
+      s->n_tri_floats = tri_floats;
+      s->n_fnrm_floats = all_fnrm.size();
       int rc;
-      if ((rc = upload(all_nodes.data(), all_nodes.size() * sizeof(DevNodeRec), &s->d_nodes, s)) ||
-          (rc = upload(all_tris.data(), all_tris.size() * sizeof(float), &s->d_tris, s)) ||
-          (rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s))) {
+      if ((rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s))) {
          release_scene(s);
          return rc;
       }
@@ -992,6 +1083,24 @@ int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[64])
    if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
    static_assert(N_STATS == 64, "mi355rt_debug_counters hands out N_STATS values");
    for (int q = 0; q < N_STATS; q++) out[q] = scene->diag[q];
+   return MI355RT_OK;
+}
+
+int mi355rt_debug_scene_digest(mi355rt_scene *scene, uint64_t out[4])
+{
+   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   const void *src[3] = { scene->d_nodes, scene->d_tris, scene->d_fnrm };
+   const size_t bytes[3] = { scene->n_node_recs * sizeof(DevNodeRec), scene->n_tri_floats * sizeof(float), scene->n_fnrm_floats * sizeof(float) };
+   for (int k = 0; k < 3; k++) {
+      std::vector<unsigned char> host(bytes[k]);
+      if (bytes[k]) HIP_TRY(hipMemcpy(host.data(), src[k], bytes[k], hipMemcpyDeviceToHost));
+      uint64_t h = 1469598103934665603ull;   // FNV-1a
+      for (unsigned char c : host) h = (h ^ c) * 1099511628211ull;
+      out[k] = h;
+   }
+   out[3] = scene->any_gpu_build ? 1u : 0u;
    return MI355RT_OK;
 }
 

@@ -1,0 +1,611 @@
+// gpu_build.hip -- the reference's hierarchy built on the GPU (second half).
+//
+// What is built is exactly what scene_build.cpp builds on the host, and what KDNode's constructor builds in the
+// reference (bounds/KDNode.java:29-90): split while depth < MAX_DEPTH and faces > MAX_CHILDREN at the midpoint of
+// the node's box on the axis cycling X -> Y -> Z; a face goes left if its max <= plane, right if its min >= plane,
+// otherwise to BOTH sides; faces keep their stored order; a child's box is the tight box of its faces; an empty side
+// is a null child.  The recursion is run level by level instead:
+//
+//   entries   (face, node) pairs of the current level, grouped by node, faces in stored order
+//   per level classify every entry against its node's plane -> exclusive scan of the (left, right) flags ->
+//             per node: child sizes -> exclusive scan over nodes: child numbering and segment starts ->
+//             stable scatter of the entries into the children's segments, tight boxes by atomic min / max on
+//             order-preserving integer keys (min and max do not depend on the order); entries of nodes that do
+//             not split are parked in the leaf store
+//   finally   subtree sizes bottom-up, DFS pre-order numbers and first-slot numbers top-down, then one kernel writes
+//             the 64-byte node records and one the 48-byte leaf slots, in the layout of layout.h.
+//
+// Every float that ends up in a record is produced by the same operation as on the host ((hi - lo) / 2 + lo for the
+// plane, min / max for the boxes), so the arrays are byte-identical to the host builder's (tests/test_gpu_build.py
+// compares them).  Java's Math.min / Math.max differ from integer-key min / max only for NaN, which the caller
+// excludes (non-finite vertices take the host builder).  One small read-back per level (child and entry totals)
+// sizes the next level's buffers.
+#include "gpu_build.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace mi355rt {
+
+namespace {
+
+constexpr unsigned NONE = 0xffffffffu;
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+constexpr float FLOAT_MAX = 3.4028234663852886e38f;
+
+struct S2 {
+   unsigned a, b;
+};
+struct S4 {
+   unsigned a, b, c, d;
+};
+__host__ __device__ inline S2 operator+(S2 x, S2 y) { return S2 { x.a + y.a, x.b + y.b }; }
+__host__ __device__ inline S4 operator+(S4 x, S4 y) { return S4 { x.a + y.a, x.b + y.b, x.c + y.c, x.d + y.d }; }
+template <typename T> __host__ __device__ inline T zero_of();
+template <> __host__ __device__ inline S2 zero_of<S2>() { return S2 { 0u, 0u }; }
+template <> __host__ __device__ inline S4 zero_of<S4>() { return S4 { 0u, 0u, 0u, 0u }; }
+
+struct BNode {   // one node of the hierarchy under construction
+   unsigned begin, count;   // its entries in its level's entry array
+   unsigned box[6];         // tight box as order-preserving keys: lo xyz (min), hi xyz (max)
+   unsigned child[2];       // global node indices, NONE = null child
+   unsigned split;          // 1: internal node
+   unsigned nl, nr;         // entries going left / right
+   unsigned store;          // leaf: first entry in the leaf store
+   unsigned n_int, n_slots, n_leaves;   // subtree totals: internal nodes, leaf slots, leaves
+   unsigned dfs, sbase;     // internal: DFS pre-order number; any: first leaf slot of the subtree
+};
+
+// order-preserving map float -> unsigned (-0 < +0, as Java's Math.min / max order them)
+__host__ __device__ inline unsigned float_key(float f)
+{
+   union {
+      float f;
+      unsigned u;
+   } c;
+   c.f = f;
+   return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+__host__ __device__ inline float key_float(unsigned k)
+{
+   union {
+      float f;
+      unsigned u;
+   } c;
+   c.u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+   return c.f;
+}
+
+// ---------------------------------------------------------------- exclusive scan (n + 1 outputs: out[n] = total)
+
+// exclusive scan of SCAN_THREADS values held one per thread; returns the thread's exclusive prefix, total in `total`
+template <typename T> __device__ inline T block_exclusive(T v, T *sh, T &total)
+{
+   sh[threadIdx.x] = v;
+   __syncthreads();
+   for (int off = 1; off < SCAN_THREADS; off <<= 1) {   // inclusive Hillis-Steele
+      T add = zero_of<T>();
+      if ((int) threadIdx.x >= off) add = sh[threadIdx.x - off];
+      __syncthreads();
+      sh[threadIdx.x] = sh[threadIdx.x] + add;
+      __syncthreads();
+   }
+   const T ex = threadIdx.x ? sh[threadIdx.x - 1] : zero_of<T>();
+   total = sh[SCAN_THREADS - 1];
+   __syncthreads();
+   return ex;
+}
+
+template <typename T> __global__ __launch_bounds__(SCAN_THREADS) void scan_block_sums(const T *in, unsigned n, T *bsum)
+{
+   __shared__ T sh[SCAN_THREADS];
+   const unsigned base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+   T acc = zero_of<T>();
+   for (int k = 0; k < SCAN_ITEMS; k++)
+      if (base + k < n) acc = acc + in[base + k];
+   T total;
+   (void) block_exclusive(acc, sh, total);
+   if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// one workgroup: exclusive scan of the block sums in place; bsum[n_blocks] = grand total
+template <typename T> __global__ __launch_bounds__(SCAN_THREADS) void scan_of_sums(T *bsum, unsigned n_blocks)
+{
+   __shared__ T sh[SCAN_THREADS];
+   T carry = zero_of<T>();   // the same in every thread
+   for (unsigned base = 0; base < n_blocks; base += SCAN_THREADS) {
+      const unsigned i = base + threadIdx.x;
+      const T v = i < n_blocks ? bsum[i] : zero_of<T>();
+      T total;
+      const T ex = block_exclusive(v, sh, total);
+      if (i < n_blocks) bsum[i] = carry + ex;
+      carry = carry + total;
+   }
+   if (threadIdx.x == 0) bsum[n_blocks] = carry;
+}
+
+template <typename T> __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const T *in, unsigned n, const T *bsum, unsigned n_blocks, T *out)
+{
+   __shared__ T sh[SCAN_THREADS];
+   const unsigned base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+   T item[SCAN_ITEMS];
+   T acc = zero_of<T>();
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      item[k] = base + k < n ? in[base + k] : zero_of<T>();
+      acc = acc + item[k];
+   }
+   T total;
+   T run = bsum[blockIdx.x] + block_exclusive(acc, sh, total);
+   for (int k = 0; k < SCAN_ITEMS; k++) {
+      if (base + k < n) out[base + k] = run;
+      run = run + item[k];
+   }
+   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[n_blocks];
+}
+
+// ---------------------------------------------------------------- set-up
+
+__global__ void face_bounds_kernel(const float *vertices, const int32_t *indices, unsigned n_faces, float *fb, unsigned *ent_face, unsigned *ent_node)
+{
+   const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
+   if (f >= n_faces) return;
+   float lo[3] = { FLOAT_MAX, FLOAT_MAX, FLOAT_MAX }, hi[3] = { -FLOAT_MAX, -FLOAT_MAX, -FLOAT_MAX };
+   for (int k = 0; k < 3; k++) {
+      const float *p = vertices + 3 * (size_t) indices[3 * (size_t) f + k];
+      for (int c = 0; c < 3; c++) {   // RTStatics.getMinMax per face (RTStatics.java:244-264); finite values: min / max as Java's
+         lo[c] = float_key(p[c]) < float_key(lo[c]) ? p[c] : lo[c];
+         hi[c] = float_key(p[c]) > float_key(hi[c]) ? p[c] : hi[c];
+      }
+   }
+   for (int c = 0; c < 3; c++) {
+      fb[6 * (size_t) f + c] = lo[c];
+      fb[6 * (size_t) f + 3 + c] = hi[c];
+   }
+   ent_face[f] = f;
+   ent_node[f] = 0u;
+}
+
+__global__ void root_kernel(BNode *nodes, unsigned n_faces, float lx, float ly, float lz, float hx, float hy, float hz)
+{
+   BNode r;
+   r.begin = 0;
+   r.count = n_faces;
+   r.box[0] = float_key(lx);
+   r.box[1] = float_key(ly);
+   r.box[2] = float_key(lz);
+   r.box[3] = float_key(hx);
+   r.box[4] = float_key(hy);
+   r.box[5] = float_key(hz);
+   r.child[0] = r.child[1] = NONE;
+   r.split = r.nl = r.nr = r.store = r.n_int = r.n_slots = r.n_leaves = r.dfs = r.sbase = 0;
+   nodes[0] = r;
+}
+
+// ---------------------------------------------------------------- one level
+
+// KDNode.java:40: does this node split?  (depth and the two limits are the same for the whole level)
+__global__ void level_split_kernel(BNode *nodes, unsigned level_off, unsigned n_nodes, int can_split, unsigned max_children)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_nodes) return;
+   BNode &nd = nodes[level_off + i];
+   nd.split = (can_split && nd.count > max_children) ? 1u : 0u;
+}
+
+// KDNode.java:45-69: which side(s) does each face of a splitting node go to
+__global__ void level_classify_kernel(const BNode *nodes, unsigned level_off, const unsigned *ent_face, const unsigned *ent_node, unsigned n_entries,
+                                      const float *fb, int axis, S2 *flags)
+{
+   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+   if (e >= n_entries) return;
+   const BNode &nd = nodes[level_off + ent_node[e]];
+   S2 fl = { 0u, 0u };
+   if (nd.split) {
+      const float lo = key_float(nd.box[axis]), hi = key_float(nd.box[3 + axis]);
+      const float plane = (hi - lo) / 2.0f + lo;
+      const float *b = fb + 6 * (size_t) ent_face[e];
+      if (b[3 + axis] <= plane) fl.a = 1u;
+      else if (b[axis] >= plane) fl.b = 1u;
+      else fl.a = fl.b = 1u;
+   }
+   flags[e] = fl;
+}
+
+// per node: sizes of the two sides; what the node contributes to the next level and to the leaf store
+__global__ void level_count_kernel(BNode *nodes, unsigned level_off, unsigned n_nodes, const S2 *scan_e, S4 *contrib)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_nodes) return;
+   BNode &nd = nodes[level_off + i];
+   S4 c = { 0u, 0u, 0u, 0u };
+   if (nd.split) {
+      const S2 a = scan_e[nd.begin], b = scan_e[nd.begin + nd.count];
+      nd.nl = b.a - a.a;
+      nd.nr = b.b - a.b;
+      c.a = (nd.nl ? 1u : 0u) + (nd.nr ? 1u : 0u);   // children
+      c.b = nd.nl + nd.nr;                          // entries of the next level
+      c.d = 1u;
+   } else {
+      c.c = nd.count;                               // entries parked in the leaf store
+   }
+   contrib[i] = c;
+}
+
+__device__ inline void init_child(BNode &ch, unsigned begin, unsigned count)
+{
+   ch.begin = begin;
+   ch.count = count;
+   ch.box[0] = ch.box[1] = ch.box[2] = 0xffffffffu;   // min keys
+   ch.box[3] = ch.box[4] = ch.box[5] = 0u;            // max keys
+   ch.child[0] = ch.child[1] = NONE;
+   ch.split = ch.nl = ch.nr = ch.store = ch.n_int = ch.n_slots = ch.n_leaves = ch.dfs = ch.sbase = 0;
+}
+
+__global__ void level_children_kernel(BNode *nodes, unsigned level_off, unsigned n_nodes, unsigned next_off, const S4 *scan_n, unsigned store_base)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_nodes) return;
+   BNode &nd = nodes[level_off + i];
+   const S4 s = scan_n[i];
+   if (!nd.split) {
+      nd.store = store_base + s.c;
+      return;
+   }
+   unsigned ci = next_off + s.a;
+   if (nd.nl) {
+      init_child(nodes[ci], s.b, nd.nl);
+      nd.child[0] = ci++;
+   }
+   if (nd.nr) {
+      init_child(nodes[ci], s.b + nd.nl, nd.nr);
+      nd.child[1] = ci;
+   }
+}
+
+// Folds the bounds of one face per active lane into its child's box.  Entries are grouped by node and keep their order,
+// so near the root a whole wave feeds the same child: then the wave reduces its 64 boxes with shuffles and issues
+// 6 atomics instead of 384 on the same words (the first levels of a 28-million-face mesh otherwise serialise on two
+// nodes' boxes).  Every lane of the wave must call it.
+__device__ inline void grow_box_wave(BNode *nodes, bool active, unsigned child, const float *b)
+{
+   const unsigned long long m = __ballot(active);
+   if (m == 0ull) return;
+   const int leader = __ffsll((unsigned long long) m) - 1;
+   const unsigned c0 = (unsigned) __shfl((int) child, leader, 64);
+   unsigned k[6];
+   for (int c = 0; c < 3; c++) {
+      k[c] = active ? float_key(b[c]) : 0xffffffffu;
+      k[3 + c] = active ? float_key(b[3 + c]) : 0u;
+   }
+   if (__ballot(active && child != c0) == 0ull) {
+      for (int off = 32; off > 0; off >>= 1) {
+         for (int c = 0; c < 3; c++) {
+            k[c] = min(k[c], (unsigned) __shfl_xor((int) k[c], off, 64));
+            k[3 + c] = max(k[3 + c], (unsigned) __shfl_xor((int) k[3 + c], off, 64));
+         }
+      }
+      if ((int) (threadIdx.x & 63) == leader) {
+         BNode &ch = nodes[c0];
+         for (int c = 0; c < 3; c++) {
+            atomicMin(&ch.box[c], k[c]);
+            atomicMax(&ch.box[3 + c], k[3 + c]);
+         }
+      }
+   } else if (active) {
+      BNode &ch = nodes[child];
+      for (int c = 0; c < 3; c++) {
+         atomicMin(&ch.box[c], k[c]);
+         atomicMax(&ch.box[3 + c], k[3 + c]);
+      }
+   }
+}
+
+// stable scatter into the children's segments (faces keep their stored order, KDNode.java:58-69), tight child boxes
+// (KDNode.java:71-85), and the entries of leaves into the leaf store
+__global__ __launch_bounds__(256) void level_scatter_kernel(BNode *nodes, unsigned level_off, unsigned next_off, const unsigned *ent_face,
+                                                            const unsigned *ent_node, unsigned n_entries, const S2 *scan_e, const float *fb,
+                                                            unsigned *next_face, unsigned *next_node, unsigned *store_face, unsigned *store_node)
+{
+   const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+   const bool live = e < n_entries;
+   bool go[2] = { false, false };
+   unsigned child[2] = { 0u, 0u };
+   const float *b = fb;
+   if (live) {
+      const unsigned g = level_off + ent_node[e];
+      const BNode &nd = nodes[g];
+      const unsigned face = ent_face[e];
+      b = fb + 6 * (size_t) face;
+      if (!nd.split) {
+         const unsigned j = nd.store + (e - nd.begin);
+         store_face[j] = face;
+         store_node[j] = g;
+      } else {
+         const S2 here = scan_e[e], next = scan_e[e + 1], first = scan_e[nd.begin];
+         go[0] = next.a != here.a;
+         go[1] = next.b != here.b;
+         child[0] = nd.child[0];
+         child[1] = nd.child[1];
+         const unsigned pos[2] = { here.a - first.a, here.b - first.b };
+         for (int s = 0; s < 2; s++) {
+            if (!go[s]) continue;
+            const unsigned dst = nodes[child[s]].begin + pos[s];
+            next_face[dst] = face;
+            next_node[dst] = child[s] - next_off;
+         }
+      }
+   }
+   grow_box_wave(nodes, go[0], child[0], b);
+   grow_box_wave(nodes, go[1], child[1], b);
+}
+
+// ---------------------------------------------------------------- layout
+
+__global__ void subtree_sizes_kernel(BNode *nodes, unsigned level_off, unsigned n_nodes)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_nodes) return;
+   BNode &nd = nodes[level_off + i];
+   if (!nd.split) {
+      nd.n_int = 0;
+      nd.n_slots = nd.count;
+      nd.n_leaves = 1;
+      return;
+   }
+   unsigned ni = 1, ns = 0, nl = 0;
+   for (int s = 0; s < 2; s++) {
+      if (nd.child[s] == NONE) continue;
+      const BNode &ch = nodes[nd.child[s]];
+      ni += ch.n_int;
+      ns += ch.n_slots;
+      nl += ch.n_leaves;
+   }
+   nd.n_int = ni;
+   nd.n_slots = ns;
+   nd.n_leaves = nl;
+}
+
+// DFS pre-order: a node, then its whole left subtree, then its right subtree (scene_build.cpp's emit order)
+__global__ void dfs_numbers_kernel(BNode *nodes, unsigned level_off, unsigned n_nodes)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_nodes) return;
+   const BNode &nd = nodes[level_off + i];
+   if (!nd.split) return;
+   unsigned dfs = nd.dfs + 1, sbase = nd.sbase;
+   for (int s = 0; s < 2; s++) {
+      if (nd.child[s] == NONE) continue;
+      BNode &ch = nodes[nd.child[s]];
+      ch.dfs = dfs;
+      ch.sbase = sbase;
+      dfs += ch.n_int;
+      sbase += ch.n_slots;
+   }
+}
+
+__global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, DevNodeRec *out)
+{
+   const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= n_all) return;
+   const BNode &nd = nodes[g];
+   if (!nd.split) return;
+   DevNodeRec r;
+   int32_t link[2] = { LINK_NONE, LINK_NONE }, cnt[2] = { 0, 0 };
+   for (int s = 0; s < 2; s++) {
+      float lo[3] = { FLOAT_MAX, FLOAT_MAX, FLOAT_MAX }, hi[3] = { -FLOAT_MAX, -FLOAT_MAX, -FLOAT_MAX };   // scene_build.cpp's null child
+      if (nd.child[s] != NONE) {
+         const BNode &ch = nodes[nd.child[s]];
+         for (int c = 0; c < 3; c++) {
+            lo[c] = key_float(ch.box[c]);
+            hi[c] = key_float(ch.box[3 + c]);
+         }
+         link[s] = (int32_t) (ch.split ? ch.dfs : ch.sbase);
+         cnt[s] = ch.split ? 0 : (int32_t) ch.count;
+      }
+      r.lo_x[s] = lo[0];
+      r.lo_y[s] = lo[1];
+      r.lo_z[s] = lo[2];
+      r.hi_x[s] = hi[0];
+      r.hi_y[s] = hi[1];
+      r.hi_z[s] = hi[2];
+   }
+   r.llink = link[0];
+   r.rlink = link[1];
+   r.lcnt = cnt[0];
+   r.rcnt = cnt[1];
+   out[nd.dfs] = r;
+}
+
+// leaf slots: { v0.xyz, faceId } { v1.xyz, faces left in the leaf from this slot on } { v2.xyz, 0 }
+__global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face, const unsigned *store_node, unsigned n_store,
+                                  const float *vertices, const int32_t *indices, float *tris)
+{
+   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+   if (j >= n_store) return;
+   const BNode &nd = nodes[store_node[j]];
+   const unsigned k = j - nd.store;
+   const unsigned face = store_face[j];
+   float4 *dst = (float4 *) tris + 3 * (size_t) (nd.sbase + k);
+   const int32_t *ix = indices + 3 * (size_t) face;
+   const float *a = vertices + 3 * (size_t) ix[0], *b = vertices + 3 * (size_t) ix[1], *c = vertices + 3 * (size_t) ix[2];
+   dst[0] = make_float4(a[0], a[1], a[2], __int_as_float((int) face));
+   dst[1] = make_float4(b[0], b[1], b[2], __int_as_float((int) (nd.count - k)));
+   dst[2] = make_float4(c[0], c[1], c[2], 0.0f);
+}
+
+__global__ void relocate_nodes_kernel(const DevNodeRec *src, unsigned n, DevNodeRec *dst, int32_t node_base, int32_t slot_base)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   DevNodeRec r = src[i];
+   if (r.llink != LINK_NONE) r.llink += r.lcnt > 0 ? slot_base : node_base;
+   if (r.rlink != LINK_NONE) r.rlink += r.rcnt > 0 ? slot_base : node_base;
+   dst[i] = r;
+}
+
+// ---------------------------------------------------------------- host driver
+
+unsigned grid_for(size_t n) { return (unsigned) ((n + 255) / 256); }
+
+// a device array that grows (contents kept)
+template <typename T> struct DevVec {
+   T *p = nullptr;
+   size_t cap = 0;
+   ~DevVec()
+   {
+      if (p) (void) hipFree(p);
+   }
+   hipError_t ensure(size_t n, size_t keep)
+   {
+      if (n <= cap) return hipSuccess;
+      const size_t want = std::max(n, cap + cap / 2);
+      T *q = nullptr;
+      hipError_t e = hipMalloc((void **) &q, want * sizeof(T));
+      if (e != hipSuccess) return e;
+      if (keep && p) e = hipMemcpy(q, p, keep * sizeof(T), hipMemcpyDeviceToDevice);
+      if (p) (void) hipFree(p);
+      p = q;
+      cap = want;
+      return e;
+   }
+};
+
+template <typename T> hipError_t exclusive_scan(const T *in, size_t n, T *out, DevVec<T> &bsum)
+{
+   const unsigned n_blocks = (unsigned) ((n + SCAN_TILE - 1) / SCAN_TILE);
+   hipError_t e = bsum.ensure((size_t) n_blocks + 1, 0);
+   if (e != hipSuccess) return e;
+   if (n_blocks) hipLaunchKernelGGL((scan_block_sums<T>), dim3(n_blocks), dim3(SCAN_THREADS), 0, nullptr, in, (unsigned) n, bsum.p);
+   hipLaunchKernelGGL((scan_of_sums<T>), dim3(1), dim3(SCAN_THREADS), 0, nullptr, bsum.p, n_blocks);
+   hipLaunchKernelGGL((scan_apply<T>), dim3(n_blocks ? n_blocks : 1), dim3(SCAN_THREADS), 0, nullptr, in, (unsigned) n, bsum.p, n_blocks, out);
+   return hipGetLastError();
+}
+
+#define GB_TRY(expr)                    \
+   do {                                 \
+      hipError_t e_ = (expr);           \
+      if (e_ != hipSuccess) return e_;  \
+   } while (0)
+
+}   // namespace
+
+void gpu_build_free(GpuBuiltObject &o)
+{
+   if (o.nodes) (void) hipFree(o.nodes);
+   if (o.tris) (void) hipFree(o.tris);
+   o = GpuBuiltObject();
+}
+
+hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, const float bmin[3],
+                            const float bmax[3], const BuildOptions &opts, GpuBuiltObject &out, std::string &err)
+{
+   out = GpuBuiltObject();
+   if (!opts.use_kdtree || n_faces <= (uint32_t) opts.max_children || opts.max_depth < 1 || n_faces > 0x3fffffffu) {
+      err = "gpu_build_object: the root must split";
+      return hipErrorInvalidValue;
+   }
+   DevVec<float> d_vertices, d_fb;
+   DevVec<int32_t> d_indices;
+   DevVec<unsigned> ent_face[2], ent_node[2], store_face, store_node;
+   DevVec<BNode> nodes;
+   DevVec<S2> flags, scan_e, bsum2;
+   DevVec<S4> contrib, scan_n, bsum4;
+   GB_TRY(d_vertices.ensure(3 * (size_t) n_vertices, 0));
+   GB_TRY(d_indices.ensure(3 * (size_t) n_faces, 0));
+   GB_TRY(d_fb.ensure(6 * (size_t) n_faces, 0));
+   GB_TRY(hipMemcpy(d_vertices.p, vertices, sizeof(float) * 3 * (size_t) n_vertices, hipMemcpyHostToDevice));
+   GB_TRY(hipMemcpy(d_indices.p, indices, sizeof(int32_t) * 3 * (size_t) n_faces, hipMemcpyHostToDevice));
+   GB_TRY(ent_face[0].ensure(n_faces, 0));
+   GB_TRY(ent_node[0].ensure(n_faces, 0));
+   GB_TRY(nodes.ensure(1024, 0));
+   hipLaunchKernelGGL(face_bounds_kernel, dim3(grid_for(n_faces)), dim3(256), 0, nullptr, d_vertices.p, d_indices.p, n_faces, d_fb.p, ent_face[0].p,
+                      ent_node[0].p);
+   hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, nullptr, nodes.p, n_faces, bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2]);
+   GB_TRY(hipGetLastError());
+
+   std::vector<unsigned> level_off { 0u }, level_n { 1u };
+   size_t n_entries = n_faces, n_all = 1, store_used = 0;
+   int cur = 0;
+   for (int depth = 0;; depth++) {
+      const unsigned off = level_off.back(), n_level = level_n.back();
+      const int can_split = depth < opts.max_depth ? 1 : 0;
+      hipLaunchKernelGGL(level_split_kernel, dim3(grid_for(n_level)), dim3(256), 0, nullptr, nodes.p, off, n_level, can_split, (unsigned) opts.max_children);
+      GB_TRY(flags.ensure(n_entries, 0));
+      GB_TRY(scan_e.ensure(n_entries + 1, 0));
+      hipLaunchKernelGGL(level_classify_kernel, dim3(grid_for(n_entries)), dim3(256), 0, nullptr, nodes.p, off, ent_face[cur].p, ent_node[cur].p,
+                         (unsigned) n_entries, d_fb.p, depth % 3, flags.p);   // RTStatics.java:50-52: X -> Y -> Z
+      GB_TRY(exclusive_scan<S2>(flags.p, n_entries, scan_e.p, bsum2));
+      GB_TRY(contrib.ensure(n_level, 0));
+      GB_TRY(scan_n.ensure((size_t) n_level + 1, 0));
+      hipLaunchKernelGGL(level_count_kernel, dim3(grid_for(n_level)), dim3(256), 0, nullptr, nodes.p, off, n_level, scan_e.p, contrib.p);
+      GB_TRY(exclusive_scan<S4>(contrib.p, n_level, scan_n.p, bsum4));
+      S4 tot;
+      GB_TRY(hipMemcpy(&tot, scan_n.p + n_level, sizeof(S4), hipMemcpyDeviceToHost));   // children, next entries, leaf entries, splits
+      if ((size_t) tot.b > 0x7ffffff0u || store_used + tot.c > 0x7ffffff0u || n_all + tot.a > 0x7ffffff0u) {
+         err = "hierarchy too large: leaf slots exceed 32-bit addressing";
+         return hipErrorInvalidValue;
+      }
+      const int nxt = cur ^ 1;
+      GB_TRY(nodes.ensure(n_all + tot.a, n_all));
+      GB_TRY(ent_face[nxt].ensure(tot.b, 0));
+      GB_TRY(ent_node[nxt].ensure(tot.b, 0));
+      GB_TRY(store_face.ensure(store_used + tot.c, store_used));
+      GB_TRY(store_node.ensure(store_used + tot.c, store_used));
+      const unsigned next_off = (unsigned) n_all;
+      hipLaunchKernelGGL(level_children_kernel, dim3(grid_for(n_level)), dim3(256), 0, nullptr, nodes.p, off, n_level, next_off, scan_n.p,
+                         (unsigned) store_used);
+      hipLaunchKernelGGL(level_scatter_kernel, dim3(grid_for(n_entries)), dim3(256), 0, nullptr, nodes.p, off, next_off, ent_face[cur].p,
+                         ent_node[cur].p, (unsigned) n_entries, scan_e.p, d_fb.p, ent_face[nxt].p, ent_node[nxt].p, store_face.p, store_node.p);
+      GB_TRY(hipGetLastError());
+      store_used += tot.c;
+      if (tot.a == 0) break;
+      level_off.push_back(next_off);
+      level_n.push_back(tot.a);
+      n_all += tot.a;
+      n_entries = tot.b;
+      cur = nxt;
+   }
+
+   for (int l = (int) level_off.size() - 1; l >= 0; l--)
+      hipLaunchKernelGGL(subtree_sizes_kernel, dim3(grid_for(level_n[l])), dim3(256), 0, nullptr, nodes.p, level_off[l], level_n[l]);
+   for (size_t l = 0; l < level_off.size(); l++)
+      hipLaunchKernelGGL(dfs_numbers_kernel, dim3(grid_for(level_n[l])), dim3(256), 0, nullptr, nodes.p, level_off[l], level_n[l]);
+   BNode root;
+   GB_TRY(hipMemcpy(&root, nodes.p, sizeof(BNode), hipMemcpyDeviceToHost));
+   if (root.n_slots != store_used || !root.split) {
+      err = "gpu_build_object: internal inconsistency (leaf store does not match the hierarchy)";
+      return hipErrorUnknown;
+   }
+   out.n_nodes = root.n_int;
+   out.n_slots = root.n_slots;
+   out.n_leaves = root.n_leaves;
+   out.max_depth = (int32_t) level_off.size() - 1;
+   GB_TRY(hipMalloc((void **) &out.nodes, sizeof(DevNodeRec) * (size_t) out.n_nodes));
+   hipError_t e = hipMalloc((void **) &out.tris, sizeof(float) * 12 * (size_t) std::max<uint64_t>(out.n_slots, 1));
+   if (e != hipSuccess) {
+      gpu_build_free(out);
+      return e;
+   }
+   hipLaunchKernelGGL(emit_nodes_kernel, dim3(grid_for(n_all)), dim3(256), 0, nullptr, nodes.p, (unsigned) n_all, out.nodes);
+   hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(store_used)), dim3(256), 0, nullptr, nodes.p, store_face.p, store_node.p, (unsigned) store_used,
+                      d_vertices.p, d_indices.p, out.tris);
+   e = hipGetLastError();
+   if (e == hipSuccess) e = hipDeviceSynchronize();
+   if (e != hipSuccess) gpu_build_free(out);
+   return e;
+}
+
+hipError_t gpu_build_relocate(const GpuBuiltObject &o, DevNodeRec *dst_nodes, float *dst_tris, int32_t node_base, int32_t slot_base)
+{
+   if (o.n_nodes)
+      hipLaunchKernelGGL(relocate_nodes_kernel, dim3(grid_for(o.n_nodes)), dim3(256), 0, nullptr, o.nodes, (unsigned) o.n_nodes, dst_nodes + node_base,
+                         node_base, slot_base);
+   hipError_t e = hipGetLastError();
+   if (e == hipSuccess && o.n_slots)
+      e = hipMemcpy(dst_tris + 12 * (size_t) slot_base, o.tris, sizeof(float) * 12 * (size_t) o.n_slots, hipMemcpyDeviceToDevice);
+   return e;
+}
+
+}   // namespace mi355rt

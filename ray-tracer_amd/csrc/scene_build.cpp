@@ -161,6 +161,8 @@ std::string build_object(const float *vertices, uint32_t n_vertices, const float
    out.shadow_distance =
        jm::fmax_java(out.bmax[0] - out.bmin[0], jm::fmax_java(out.bmax[1] - out.bmin[1], out.bmax[2] - out.bmin[2])) / 2000.0f;
 
+   if (!opts.build_tree) return std::string();
+
    std::vector<FaceBounds> fb((size_t) n_faces);
    for (uint32_t f = 0; f < n_faces; f++) {
       FaceBounds &b = fb[f];

@@ -12,6 +12,7 @@ struct BuildOptions {
    int max_depth = 20;
    int max_children = 5;
    bool use_kdtree = true;
+   bool build_tree = true;   // false: validate, normals and bounds only (the hierarchy comes from gpu_build.hip)
 };
 
 struct BuiltObject {

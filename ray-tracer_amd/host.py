@@ -349,6 +349,12 @@ class Scene:
         return {"minmax": np.array(mm[:], dtype=np.float32), "shadow_distance": np.float32(sd.value),
                 "n_nodes": nn.value, "n_leaves": nl.value, "n_leaf_slots": ns.value, "max_depth": md.value}
 
+    def digest(self):
+        """mi355rt_debug_scene_digest: (nodes, leaf slots, normals) digests and whether any mesh was built on the GPU."""
+        out = (C.c_uint64 * 4)()
+        _abi.check(self._lib.mi355rt_debug_scene_digest(self._handle, out))
+        return (out[0], out[1], out[2]), bool(out[3])
+
     def device_bytes(self):
         b = C.c_uint64()
         _abi.check(self._lib.mi355rt_scene_device_bytes(self._handle, C.byref(b)))
