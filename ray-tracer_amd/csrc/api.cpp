@@ -688,6 +688,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             }
             // leaf slots: 3 x float4 per (leaf, face): { v0, faceId } { v1, faces left in the leaf } { v2, 0 }
             part.tris.assign(12 * bo_out.slot_face.size(), 0.0f);
+            int32_t in_leaf = 0;
             for (size_t sidx = 0; sidx < bo_out.slot_face.size(); sidx++) {
                const int32_t f = bo_out.slot_face[sidx];
                float *dst = part.tris.data() + 12 * sidx;
@@ -701,6 +702,8 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
                std::memcpy(&dst[3], &f, sizeof(float));
                const int32_t remaining = bo_out.slot_remaining[sidx];
                std::memcpy(&dst[7], &remaining, sizeof(float));
+               in_leaf = (sidx == 0 || bo_out.slot_remaining[sidx - 1] == 1) ? 0 : in_leaf + 1;   // a leaf ends on the slot with 1 face left
+               std::memcpy(&dst[11], &in_leaf, sizeof(float));
             }
          }
          node_total += part.n_nodes;

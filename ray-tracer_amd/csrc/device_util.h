@@ -149,6 +149,26 @@ __device__ __forceinline__ bool tri_test(const float4 A, const float4 B, const f
    return true;
 }
 
+// The tests of Triangle.intersectsTriangle alone (Triangle.java:85-124): does the ray meet this face at all?  The
+// closest-hit walker asks only this in its leaf loop and leaves the point and distance of the few faces that pass to
+// a later, batched tri_test (same arithmetic, so the same answer).
+__device__ __forceinline__ bool tri_meets(const float4 A, const float4 B, const float4 C, const Ray &r, float eps)
+{
+   const V3 p0 = mk3(A.x, A.y, A.z);
+   const V3 e1 = sub3(mk3(B.x, B.y, B.z), p0);
+   const V3 e2 = sub3(mk3(C.x, C.y, C.z), p0);
+   const V3 p = cross3(r.d, e2);
+   const float divisor = dot3(p, e1);
+   if ((divisor < eps) && (divisor > -eps)) return false;
+   const V3 T = sub3(r.o, p0);
+   const V3 q = cross3(T, e1);
+   const float u = dot3(p, T) / divisor;
+   if ((u < 0) || (u > 1)) return false;
+   const float v = dot3(q, r.d) / divisor;
+   if ((v < 0) || (v + u > 1)) return false;
+   return true;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -418,7 +418,7 @@ __global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, DevNodeRec
    out[nd.dfs] = r;
 }
 
-// leaf slots: { v0.xyz, faceId } { v1.xyz, faces left in the leaf from this slot on } { v2.xyz, 0 }
+// leaf slots: { v0.xyz, faceId } { v1.xyz, faces left in the leaf from this slot on } { v2.xyz, index of the slot in its leaf }
 __global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face, const unsigned *store_node, unsigned n_store,
                                   const float *vertices, const int32_t *indices, float *tris)
 {
@@ -432,7 +432,7 @@ __global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face
    const float *a = vertices + 3 * (size_t) ix[0], *b = vertices + 3 * (size_t) ix[1], *c = vertices + 3 * (size_t) ix[2];
    dst[0] = make_float4(a[0], a[1], a[2], __int_as_float((int) face));
    dst[1] = make_float4(b[0], b[1], b[2], __int_as_float((int) (nd.count - k)));
-   dst[2] = make_float4(c[0], c[1], c[2], 0.0f);
+   dst[2] = make_float4(c[0], c[1], c[2], __int_as_float((int) k));
 }
 
 __global__ void relocate_nodes_kernel(const DevNodeRec *src, unsigned n, DevNodeRec *dst, int32_t node_base, int32_t slot_base)

@@ -20,7 +20,7 @@
 //   tris  : one 48-byte slot per (leaf, face) pair, leaves in left-to-right DFS order, faces in
 //           the reference's stored order (straddlers are duplicated exactly as KDNode.java:58-69
 //           duplicates them).  slot = 3 x float4 { v0.xyz, faceId }, { v1.xyz, faces left in this leaf },
-//           { v2.xyz, 0 }; LEAF_PAD_SLOTS zero slots follow the last leaf.
+//           { v2.xyz, index of the slot within its leaf }; LEAF_PAD_SLOTS zero slots follow the last leaf.
 //           Because leaves are laid out in DFS order, the first-slot index of a leaf is also the
 //           leaf's rank in the reference's fold order (the tie rule of KDNode.java:105,114).
 //   fnrm  : 48 bytes per FACE (not per slot): the three vertex normals, fetched once per final hit.

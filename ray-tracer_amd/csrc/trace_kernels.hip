@@ -361,6 +361,7 @@ struct WalkArgs {
    int32_t tail_steal_min;   // once the queue is dry: steal with this many idle lanes
    int32_t age_min;      // shadow modes: idle lanes help a ray that has been walked for this many trips at once
    int32_t both_min;     // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
+   int32_t resolve_min;  // MODE_CLOSEST: faces that passed the triangle tests wait in their lanes until this many lanes hold one
 };
 
 // lane roles
@@ -419,6 +420,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    int cur = STACK_EMPTY;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
+   int pend = -1;         // MODE_CLOSEST: a face of the current object that passed the triangle tests and whose point and
+                          // distance are still to be computed: slot * 2 + (the next slot passed too); see "resolve" below
+   bool resolve_req = false;   // wave-uniform: some lane found a second such face
    float lim2 = 0.0f;
    float ob_w = 0.0f, best_w = 0.0f;
    int ob_slot = -1, ob_key = 0, best_slot = -1, best_obj = -1;
@@ -435,6 +439,38 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    for (;;) {
       if (STATS > 1 && lane == 0) d_outer++;
       if (STATS && exhausted) d_tail_trips++;
+      // ---- resolve: most faces fail the triangle tests; computing the point and distance of the one or two per wave
+      // and trip that pass, right there, ran some forty instructions for a lane or two twice a trip.  The leaf loop
+      // only notes the slot; here, once enough lanes hold one (or a lane needs its answer: its walk of the object is
+      // over, or it found another face), all of them are worked out together and folded into the lane's best.  The
+      // fold does not depend on when it happens (see the tie rule), and slots of one leaf still arrive in slot order.
+      if (MODE == MODE_CLOSEST) {
+         const unsigned long long pm = __ballot(pend >= 0);
+         if (pm != 0ull && (resolve_req || exhausted || __popcll(pm) >= a.resolve_min || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
+            const float sd = st.k >= 0 ? a.sc.objs[st.k].shadow_distance : 0.0f;
+            for (int pass = 0; pass < 2; pass++) {
+               const bool doit = pend >= 0 && (pass == 0 || (pend & 1));
+               if (pass == 1 && __ballot(doit) == 0ull) break;
+               if (doit) {
+                  const int slot = (pend >> 1) + pass;
+                  const float4 *t = tris + 3 * (size_t) slot;
+                  const float4 A = t[0], B = t[1], C = t[2];
+                  float u, v, dist;
+                  V3 P;
+                  (void) tri_test(A, B, C, r, eps, u, v, P, dist);
+                  const int key = slot - __float_as_int(C.w);   // first slot of the face's leaf
+                  if ((dist > sd) && (ob_slot < 0 || dist < ob_w || (dist == ob_w && key > ob_key))) {
+                     ob_w = dist;
+                     ob_slot = slot;
+                     ob_key = key;
+                     lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
+                  }
+               }
+            }
+            pend = -1;
+            resolve_req = false;
+         }
+      }
       if (__ballot(cur == STACK_EMPTY) != 0ull) {
          // ---- (1) helpers that finished their subtree hand (w, slot, leaf) to the ray's owner, which
          // folds it in with the same order-independent rule the leaves use
@@ -788,6 +824,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          }
          const int n_left = __float_as_int(q[1].w);
          bool stop = n_left <= LEAF_BATCH;
+         bool advance = true;
+         if (MODE == MODE_CLOSEST) {
+            static_assert(LEAF_BATCH == 2, "the pending-face word holds one slot and a flag for the next");
+            if (STATS) n_tri += n_left > 1 ? 2u : 1u;
+            const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
+            const bool m1 = n_left > 1 && tri_meets(q[3], q[4], q[5], r, eps);
+            if (m0 || m1) {
+               if (pend < 0) {
+                  pend = ((s + (m0 ? 0 : 1)) << 1) | ((m0 && m1) ? 1 : 0);
+               } else {
+                  advance = false;   // one waits already: it is worked out first, then this pair of faces is tested again
+               }
+            }
+            resolve_req = __ballot(!advance) != 0ull;
+         } else {
 #pragma unroll
          for (int j = 0; j < LEAF_BATCH; j++) {
             if (j < n_left) {
@@ -808,6 +859,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                }
             }
          }
+         }
+         if (advance) {
          s += LEAF_BATCH;
          if (stop) {
             if (sp > bot) {
@@ -817,6 +870,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                cur = STACK_EMPTY;
             }
             s = ~cur;
+         }
          }
       }
    }
@@ -1276,6 +1330,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
+   a.resolve_min = tunable("MI355RT_RESOLVE_MIN", 12);
    a.age_min = tunable("MI355RT_AGE_MIN_CLOSEST", 1 << 30);
    return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, 6)), stats ? (diag ? 2 : 1) : 0, stream);
 }
@@ -1327,6 +1382,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.steal_min = tunable("MI355RT_STEAL_MIN_SHADOW", 64);
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
+   a.resolve_min = 1;
    a.age_min = tunable("MI355RT_AGE_MIN", 8);
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
