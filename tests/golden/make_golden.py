@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle  # noqa: E402
 import ray_tracer_amd as rt  # noqa: E402
-from helpers import synthetic_brdf_tables  # noqa: E402
+from helpers import CORNELL_LIGHT, LIGHT, _both_sides, cornell_box, synthetic_brdf_tables, whitted_objects  # noqa: E402
 
 CASES = {
     # name: (mesh spec, material kind, frame WxH, spp, lighting, orientation, fov)
@@ -28,6 +28,36 @@ CASES = {
     "blob3k_plain_large": dict(faces=3000, span=400.0, seed=4, stretch=(0.59, 1.0, 0.52), W=40, H=48, ms=1, phong=0, orient=(0, 0, 0), fov=10.0),
     "blob2k_brdf": dict(faces=2500, span=0.2, seed=3, stretch=(0.41, 1.0, 0.41), W=32, H=48, ms=1, phong=1, orient=(180, 0, 0), fov=10.0, brdf=3),
 }
+
+
+# the reference's own analytic scenes (RayTracer.java:111-113,147-149,155-235): spheres, planes, glass, mirror, checkerboard
+ANALYTIC_CASES = {
+    "whitted_phong": dict(objects=lambda: whitted_objects(rt, False), W=64, H=48, ms=2, orient=(0, 0, 0), fov=35.0, light=LIGHT),
+    "cornell_phong": dict(objects=lambda: cornell_box(rt, True, True), W=48, H=48, ms=1, orient=(180, 0, 0), fov=15.0, light=CORNELL_LIGHT),
+}
+
+
+def build_analytic(case):
+    """(host objects, oracle scene) of an analytic case."""
+    sides = [_both_sides(o, True) for o in case["objects"]()]
+    return [h for h, _ in sides], oracle.OracleScene([o for _, o in sides])
+
+
+def analytic_settings(case, eps):
+    lt = case["light"]
+    return oracle.settings(epsilon=eps, ms=case["ms"], lighting=1, seed=99, light_origin=lt["origin"], light_emission=lt["emission"],
+                           light_ambient=lt["ambient"])
+
+
+def analytic_rays(case, sc):
+    """Rays aimed into the scene's bounds from around it."""
+    rs = np.random.RandomState(4321)
+    mm = np.array([sc.object_info(k)["minmax"] for k in range(sc.n_objs)])
+    lo, hi = mm[:, :3].min(axis=0), mm[:, 3:].max(axis=0)
+    n = 400
+    o = (lo + rs.uniform(-0.3, 1.3, size=(n, 3)) * (hi - lo)).astype(np.float32)
+    tgt = (lo + rs.uniform(0.1, 0.9, size=(n, 3)) * (hi - lo)).astype(np.float32)
+    return o, (tgt - o).astype(np.float32)
 
 
 def build(case):
@@ -64,5 +94,24 @@ def main():
         sc.close()
 
 
+def main_analytic():
+    for name, case in ANALYTIC_CASES.items():
+        _, sc = build_analytic(case)
+        eps = sc.epsilon()
+        cam = sc.camera(case["orient"], case["fov"], 0.01, case["W"], case["H"])
+        st = analytic_settings(case, eps)
+        fr = sc.render(cam, st, n_threads=1)
+        o, d = analytic_rays(case, sc)
+        tr = sc.trace(st, o, d)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"),
+                            cam_origin=np.array(cam.origin[:], dtype=np.float32), cam_rotation=np.array(cam.rotation[:], dtype=np.float32),
+                            epsilon=np.float32(eps), rgb=fr["rgb"], hit_obj=fr["hit_obj"], hit_w=fr["hit_w"],
+                            ray_o=o, ray_d=d, ray_object=tr["object"], ray_w=tr["w"], ray_point=tr["point"], ray_normal=tr["normal"])
+        print(name, "hits", int((fr["hit_obj"] >= 0).sum()), "objects seen", sorted(set(fr["hit_obj"].ravel().tolist())),
+              "ray hits", int((tr["object"] >= 0).sum()))
+        sc.close()
+
+
 if __name__ == "__main__":
+    main_analytic()
     main()

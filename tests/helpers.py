@@ -88,3 +88,52 @@ def compare_frames(g_rgb, g_id, g_w, o, rtol=1e-3, atol=1e-6):
     denom = np.maximum(np.abs(o["rgb"]), atol / rtol)
     rel = np.abs(g_rgb - o["rgb"]) / denom
     return ids_equal, w_equal, float(rel.max()), int((g_id != o["hit_id"]).sum())
+
+
+# ---------------------------------------------------------------- the reference's analytic scenes (shared with tests/golden/make_golden.py)
+
+YELLOW, RED, BLUE, GRAY, GREEN, CYAN, WHITE = (1, 1, 0), (1, 0, 0), (0, 0, 1), (128 / 255.0,) * 3, (0, 1, 0), (0, 1, 1), (1, 1, 1)
+
+
+def whitted_objects(rt, use_brdfs):
+    """RayTracer.getWhittedObjects (RayTracer.java:155-167)."""
+    plane = rt.Plane([(-50, 0, -100), (-50, -40, 25), (50, -40, 25), (50, 0, -100)], rt.CheckerboardMaterial(YELLOW, RED, 10.0, 10.0, 10.0))
+    blue = rt.ReflectionMaterial(BLUE)
+    glass = rt.RefractionMaterial(GRAY, rt.RefractionMaterial.INDEX_OF_GLASS)
+    s1 = rt.Sphere(5, (0, -12, 0), rt.BRDFMaterial(15, GREEN) if use_brdfs else glass)
+    s2 = rt.Sphere(3, (5, -15, -10), rt.BRDFMaterial(16, CYAN) if use_brdfs else blue)
+    return [plane, s1, s2]
+
+
+def cornell_box(rt, use_spheres, use_whitted_materials):
+    """RayTracer.getCornellBox (RayTracer.java:176-235)."""
+    white, white2 = rt.ColorInformation((0.75, 0.75, 0.75)), rt.ColorInformation((0.65, 0.65, 0.65))
+    red, green = rt.ColorInformation((0.63, 0.06, 0.04)), rt.ColorInformation((0.15, 0.48, 0.09))
+    blue = rt.ColorInformation((0.392, 0.584, 0.93))
+    mirror, glass = rt.ReflectionMaterial(WHITE), rt.RefractionMaterial(BLUE, rt.RefractionMaterial.INDEX_OF_GLASS)
+    (x0, y0, z0), (x1, y1, z1) = (-278, -275, -800), (278, 275, 280)
+    objs = [rt.Plane([(x1, y0, z0), (x0, y0, z0), (x0, y0, z1), (x1, y0, z1)], white),    # floor
+            rt.Plane([(x1, y1, z0), (x1, y1, z1), (x0, y1, z1), (x0, y1, z0)], white),    # ceiling
+            rt.Plane([(x1, y0, z1), (x0, y0, z1), (x0, y1, z1), (x1, y1, z1)], white),    # back
+            rt.Plane([(x1, y0, z0), (x0, y0, z0), (x0, y1, z0), (x1, y1, z0)], white),    # front
+            rt.Plane([(x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0)], red),      # left
+            rt.Plane([(x0, y0, z1), (x0, y0, z0), (x0, y1, z0), (x0, y1, z1)], green)]    # right
+    if use_spheres:
+        objs += [rt.Sphere(82.5, (-92, -192.5, -111.5), glass if use_whitted_materials else blue),
+                 rt.Sphere(82.5, (116.5, -192.5, 71.5), mirror if use_whitted_materials else blue)]
+    else:
+        small = [[(-148, -110, -215), (-196, -110, -55), (-32, -110, -8), (12, -110, -166)],
+                 [(12, -275, -166), (12, -110, -166), (-32, -110, -8), (-32, -275, -8)],
+                 [(-148, -275, -215), (-148, -110, -215), (12, -110, -166), (12, -275, -166)],
+                 [(-196, -275, -55), (-196, -110, -55), (-148, -110, -215), (-148, -275, -215)],
+                 [(-32, -275, -8), (-32, -110, -8), (-196, -110, -55), (-196, -275, -55)]]
+        large = [[(145, 55, -33), (-13, 55, 16), (36, 55, 176), (194, 55, 126)],
+                 [(145, -275, -33), (145, 55, -33), (194, 55, 126), (194, -275, 126)],
+                 [(194, -275, 126), (194, 55, 126), (36, 55, 176), (36, -275, 176)],
+                 [(36, -275, 176), (36, 55, 176), (-13, 55, 16), (-13, -275, 16)],
+                 [(-13, -275, 16), (-13, 55, 16), (145, 55, -33), (145, -275, -33)]]
+        objs += [rt.Plane(c, white2) for c in small + large]
+    return objs
+
+
+CORNELL_LIGHT = dict(origin=(0.0, 270.0, 0.0), emission=(0.75, 0.75, 0.75), ambient=(0.75, 0.75, 0.75))   # RayTracer.java:109

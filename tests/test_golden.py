@@ -69,3 +69,51 @@ def test_hip_reproduces_golden(rt, name):
     np.testing.assert_array_equal(tr["point"][hit].view(np.uint32), g["ray_point"][hit].view(np.uint32))
     np.testing.assert_array_equal(tr["normal"][hit].view(np.uint32), g["ray_normal"][hit].view(np.uint32))
     scene.close()
+
+
+ANALYTIC_NAMES = sorted(make_golden.ANALYTIC_CASES)
+
+
+@pytest.mark.parametrize("name", ANALYTIC_NAMES)
+def test_oracle_reproduces_analytic_golden(orc, name):
+    g = _load(name)
+    case = make_golden.ANALYTIC_CASES[name]
+    _, sc = make_golden.build_analytic(case)
+    assert np.float32(sc.epsilon()) == g["epsilon"]
+    cam = sc.camera(case["orient"], case["fov"], 0.01, case["W"], case["H"])
+    np.testing.assert_array_equal(np.array(cam.origin[:], dtype=np.float32), g["cam_origin"])
+    fr = sc.render(cam, make_golden.analytic_settings(case, float(g["epsilon"])), n_threads=2)
+    np.testing.assert_array_equal(fr["hit_obj"], g["hit_obj"])
+    np.testing.assert_array_equal(fr["hit_w"].view(np.uint32), g["hit_w"].view(np.uint32))
+    np.testing.assert_array_equal(fr["rgb"].view(np.uint32), g["rgb"].view(np.uint32))
+    tr = sc.trace(make_golden.analytic_settings(case, float(g["epsilon"])), g["ray_o"], g["ray_d"])
+    np.testing.assert_array_equal(tr["object"], g["ray_object"])
+    np.testing.assert_array_equal(tr["w"].view(np.uint32), g["ray_w"].view(np.uint32))
+    sc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ANALYTIC_NAMES)
+def test_hip_reproduces_analytic_golden(rt, name):
+    g = _load(name)
+    case = make_golden.ANALYTIC_CASES[name]
+    objs, osc = make_golden.build_analytic(case)
+    osc.close()
+    lt = case["light"]
+    light = rt.Light(lt["origin"], lt["emission"], lt["ambient"])
+    scene = rt.Scene(objs, light, case["orient"], rt.PhongLightingModel(light, objs), case["fov"])
+    assert np.float32(rt.RTStatics.EPSILON) == g["epsilon"]
+    cam = rt.Camera(scene, case["ms"], 1, rt.RTStatics.NEAR_PLANE, case["W"], case["H"], rng_seed=99)
+    np.testing.assert_array_equal(cam.origin, g["cam_origin"])
+    np.testing.assert_array_equal(cam.rotation.ravel(), g["cam_rotation"])
+    cam.createImage()
+    np.testing.assert_array_equal(cam.hit_id.T >= 0, g["hit_obj"] >= 0)
+    np.testing.assert_array_equal(cam.hit_w.T.view(np.uint32), g["hit_w"].view(np.uint32))
+    denom = np.maximum(np.abs(g["rgb"]), 1e-3)
+    assert float((np.abs(cam._rgb_rows - g["rgb"]) / denom).max()) <= 1e-3      # north star: radiance within 1e-3 relative
+    tr = cam.getClosestIntersection(g["ray_o"], g["ray_d"])
+    np.testing.assert_array_equal(tr["object"], g["ray_object"])
+    hit = g["ray_object"] >= 0
+    for key in ("w", "point", "normal"):
+        np.testing.assert_array_equal(tr[key][hit].view(np.uint32), g["ray_" + key][hit].view(np.uint32))
+    scene.close()
