@@ -296,6 +296,108 @@ std::string add_analytic_object(mi355rt_scene *s, const mi355rt_object_desc &od,
    return std::string();
 }
 
+// One mesh's share of the scene's node and leaf-slot arrays: built on the host (scene_build.cpp) or on the GPU
+// (gpu_build.hip), copied to its place once every object's size is known.
+struct ScenePart {
+   std::vector<DevNodeRec> nodes;   // host-built: records with absolute links
+   std::vector<float> tris;         // host-built: 12 floats per slot
+   GpuBuiltObject gpu;              // GPU-built: device buffers with relative links
+   bool on_gpu = false;
+   size_t node_base = 0, slot_base = 0, n_nodes = 0, n_slots = 0;
+};
+
+// The host builder's output as the uploaded records (layout.h): node records with both children interleaved and
+// absolute links, and one 48-byte slot per (leaf, face).
+void host_part_records(const BuiltObject &built, const mi355rt_mesh_desc &md, ScenePart &part, bool &boxes_finite)
+{
+   part.nodes.reserve(built.nodes.size());
+   for (NodeRec rec : built.nodes) {
+      if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? part.slot_base : part.node_base);
+      if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? part.slot_base : part.node_base);
+      DevNodeRec d;
+      const float *lo[2] = { rec.lmin, rec.rmin }, *hi[2] = { rec.lmax, rec.rmax };
+      for (int side = 0; side < 2; side++) {
+         d.lo_x[side] = lo[side][0];
+         d.lo_y[side] = lo[side][1];
+         d.lo_z[side] = lo[side][2];
+         d.hi_x[side] = hi[side][0];
+         d.hi_y[side] = hi[side][1];
+         d.hi_z[side] = hi[side][2];
+         for (int c = 0; c < 3; c++) boxes_finite = boxes_finite && std::isfinite(lo[side][c]) && std::isfinite(hi[side][c]);
+      }
+      d.llink = rec.llink;
+      d.rlink = rec.rlink;
+      d.lcnt = rec.lcnt;
+      d.rcnt = rec.rcnt;
+      part.nodes.push_back(d);
+   }
+   // leaf slots: { v0, faceId } { v1, faces left in the leaf } { v2, index of the slot in its leaf }
+   part.tris.assign(12 * built.slot_face.size(), 0.0f);
+   int32_t in_leaf = 0;
+   for (size_t sidx = 0; sidx < built.slot_face.size(); sidx++) {
+      const int32_t f = built.slot_face[sidx];
+      float *dst = part.tris.data() + 12 * sidx;
+      for (int kx = 0; kx < 3; kx++) {
+         const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
+         dst[4 * kx + 0] = v[0];
+         dst[4 * kx + 1] = v[1];
+         dst[4 * kx + 2] = v[2];
+         dst[4 * kx + 3] = 0.0f;
+      }
+      std::memcpy(&dst[3], &f, sizeof(float));
+      const int32_t remaining = built.slot_remaining[sidx];
+      std::memcpy(&dst[7], &remaining, sizeof(float));
+      in_leaf = (sidx == 0 || built.slot_remaining[sidx - 1] == 1) ? 0 : in_leaf + 1;   // a leaf ends on the slot with 1 face left
+      std::memcpy(&dst[11], &in_leaf, sizeof(float));
+   }
+}
+
+// 48 bytes per face: the three vertex normals, fetched once per final hit
+void append_face_normals(std::vector<float> &all_fnrm, size_t face_base, const mi355rt_mesh_desc &md, const std::vector<float> &normals)
+{
+   all_fnrm.resize(12 * (face_base + md.n_faces), 0.0f);
+   for (size_t f = 0; f < md.n_faces; f++) {
+      float *dst = all_fnrm.data() + 12 * (face_base + f);
+      for (int kx = 0; kx < 3; kx++) {
+         const float *nrm = normals.data() + 3 * (size_t) md.indices[3 * f + kx];
+         dst[4 * kx + 0] = nrm[0];
+         dst[4 * kx + 1] = nrm[1];
+         dst[4 * kx + 2] = nrm[2];
+      }
+   }
+}
+
+// Allocates the scene's node and leaf-slot arrays and copies every part to its place.  LEAF_PAD_SLOTS zero slots
+// (one face left) follow the last leaf: a walker reads a few slots past a leaf's end.
+hipError_t upload_parts(mi355rt_scene *s, std::vector<ScenePart> &parts, size_t node_total, size_t slot_total)
+{
+   const size_t node_bytes = std::max<size_t>(node_total, 1) * sizeof(DevNodeRec);
+   const size_t tri_floats = 12 * (slot_total + LEAF_PAD_SLOTS);
+   hipError_t e = hipMalloc(&s->d_nodes, node_bytes);
+   if (e == hipSuccess) e = hipMalloc(&s->d_tris, tri_floats * sizeof(float));
+   if (e != hipSuccess) return e;
+   s->device_bytes += node_bytes + tri_floats * sizeof(float);
+   s->n_node_recs = node_total;
+   s->n_tri_floats = tri_floats;
+   std::vector<float> pad(12 * (size_t) LEAF_PAD_SLOTS, 0.0f);
+   const int32_t one = 1;
+   for (int q = 0; q < LEAF_PAD_SLOTS; q++) std::memcpy(&pad[12 * (size_t) q + 7], &one, sizeof(float));
+   e = hipMemcpy((float *) s->d_tris + 12 * slot_total, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice);
+   for (ScenePart &part : parts) {
+      if (e != hipSuccess) break;
+      if (part.on_gpu) {
+         e = gpu_build_relocate(part.gpu, (DevNodeRec *) s->d_nodes, (float *) s->d_tris, (int32_t) part.node_base, (int32_t) part.slot_base);
+      } else {
+         if (!part.nodes.empty())
+            e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, part.nodes.data(), part.nodes.size() * sizeof(DevNodeRec), hipMemcpyHostToDevice);
+         if (e == hipSuccess && !part.tris.empty())
+            e = hipMemcpy((float *) s->d_tris + 12 * part.slot_base, part.tris.data(), part.tris.size() * sizeof(float), hipMemcpyHostToDevice);
+      }
+   }
+   if (e == hipSuccess) e = hipDeviceSynchronize();
+   return e;
+}
+
 // a pass renders at most this many sample slots at once (bounds the scratch: ~104 B per slot,
 // ~204 B with mirrors, 144 B more with a RefractionMaterial)
 constexpr size_t PASS_SLOTS = (size_t) 1 << 24;
@@ -580,16 +682,9 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
    std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
    // all objects share one node array, one slot array and one normal array (links absolute); each object's part is
    // built on the host (scene_build.cpp) or on the GPU (gpu_build.hip) and copied to its place at the end
-   struct Part {
-      std::vector<DevNodeRec> nodes;   // host-built: records with absolute links
-      std::vector<float> tris;         // host-built: 12 floats per slot
-      GpuBuiltObject gpu;              // GPU-built: device buffers with relative links
-      bool on_gpu = false;
-      size_t node_base = 0, slot_base = 0, n_nodes = 0, n_slots = 0;
-   };
-   std::vector<Part> parts(n_meshes ? n_meshes : 1);
+   std::vector<ScenePart> parts(n_meshes ? n_meshes : 1);
    auto free_parts = [&parts]() {
-      for (Part &p : parts) gpu_build_free(p.gpu);
+      for (ScenePart &p : parts) gpu_build_free(p.gpu);
    };
    bool boxes_finite = true;
    std::vector<float> all_fnrm;
@@ -617,7 +712,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             }
             continue;
          }
-         Part &part = parts[i];
+         ScenePart &part = parts[i];
          // The GPU builder takes every mesh whose root splits and whose vertices are all finite (Java's Math.min / max
          // treat NaN specially; the host builder restates that, the GPU's integer-key min / max do not).
          bool gpu_build = allow_gpu_build && bo.use_kdtree && bo.max_depth >= 1 && md.n_faces > (uint32_t) std::max(bo.max_children, 0) &&
@@ -664,48 +759,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             release_scene(s);
             return fail(MI355RT_E_LIMIT, "scene exceeds 2^31 nodes, leaf slots or faces");
          }
-         if (!gpu_build) {
-            part.nodes.reserve(bo_out.nodes.size());
-            for (NodeRec rec : bo_out.nodes) {
-               if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? slot_base : node_base);
-               if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? slot_base : node_base);
-               DevNodeRec d;
-               const float *lo[2] = { rec.lmin, rec.rmin }, *hi[2] = { rec.lmax, rec.rmax };
-               for (int side = 0; side < 2; side++) {
-                  d.lo_x[side] = lo[side][0];
-                  d.lo_y[side] = lo[side][1];
-                  d.lo_z[side] = lo[side][2];
-                  d.hi_x[side] = hi[side][0];
-                  d.hi_y[side] = hi[side][1];
-                  d.hi_z[side] = hi[side][2];
-                  for (int c = 0; c < 3; c++) boxes_finite = boxes_finite && std::isfinite(lo[side][c]) && std::isfinite(hi[side][c]);
-               }
-               d.llink = rec.llink;
-               d.rlink = rec.rlink;
-               d.lcnt = rec.lcnt;
-               d.rcnt = rec.rcnt;
-               part.nodes.push_back(d);
-            }
-            // leaf slots: 3 x float4 per (leaf, face): { v0, faceId } { v1, faces left in the leaf } { v2, 0 }
-            part.tris.assign(12 * bo_out.slot_face.size(), 0.0f);
-            int32_t in_leaf = 0;
-            for (size_t sidx = 0; sidx < bo_out.slot_face.size(); sidx++) {
-               const int32_t f = bo_out.slot_face[sidx];
-               float *dst = part.tris.data() + 12 * sidx;
-               for (int kx = 0; kx < 3; kx++) {
-                  const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
-                  dst[4 * kx + 0] = v[0];
-                  dst[4 * kx + 1] = v[1];
-                  dst[4 * kx + 2] = v[2];
-                  dst[4 * kx + 3] = 0.0f;
-               }
-               std::memcpy(&dst[3], &f, sizeof(float));
-               const int32_t remaining = bo_out.slot_remaining[sidx];
-               std::memcpy(&dst[7], &remaining, sizeof(float));
-               in_leaf = (sidx == 0 || bo_out.slot_remaining[sidx - 1] == 1) ? 0 : in_leaf + 1;   // a leaf ends on the slot with 1 face left
-               std::memcpy(&dst[11], &in_leaf, sizeof(float));
-            }
-         }
+         if (!gpu_build) host_part_records(bo_out, md, part, boxes_finite);
          node_total += part.n_nodes;
          slot_total += part.n_slots;
          if (getenv("MI355RT_BUILD_TIMING")) {   // profiling aid
@@ -714,16 +768,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
                          gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
                          gpu_build ? "GPU hierarchy" : "records", std::chrono::duration<double>(t_end - t_tree).count());
          }
-         all_fnrm.resize(12 * (face_base + md.n_faces), 0.0f);
-         for (size_t f = 0; f < md.n_faces; f++) {
-            float *dst = all_fnrm.data() + 12 * (face_base + f);
-            for (int kx = 0; kx < 3; kx++) {
-               const float *nrm = bo_out.normals.data() + 3 * (size_t) md.indices[3 * f + kx];
-               dst[4 * kx + 0] = nrm[0];
-               dst[4 * kx + 1] = nrm[1];
-               dst[4 * kx + 2] = nrm[2];
-            }
-         }
+         append_face_normals(all_fnrm, face_base, md, bo_out.normals);
          face_total += md.n_faces;
 
          s->objects.emplace_back();
@@ -765,40 +810,14 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
    }
    {
-      // the shared arrays; LEAF_PAD_SLOTS zero slots (one face left) follow the last leaf: a walker reads a few slots past a leaf's end
-      const size_t node_bytes = std::max<size_t>(node_total, 1) * sizeof(DevNodeRec);
-      const size_t tri_floats = 12 * (slot_total + LEAF_PAD_SLOTS);
-      hipError_t e = hipMalloc(&s->d_nodes, node_bytes);
-      if (e == hipSuccess) e = hipMalloc(&s->d_tris, tri_floats * sizeof(float));
-      if (e == hipSuccess) {
-         s->device_bytes += node_bytes + tri_floats * sizeof(float);
-         std::vector<float> pad(12 * (size_t) LEAF_PAD_SLOTS, 0.0f);
-         const int32_t one = 1;
-         for (int q = 0; q < LEAF_PAD_SLOTS; q++) std::memcpy(&pad[12 * (size_t) q + 7], &one, sizeof(float));
-         e = hipMemcpy((float *) s->d_tris + 12 * slot_total, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice);
-      }
-      for (Part &part : parts) {
-         if (e != hipSuccess) break;
-         if (part.on_gpu) {
-            e = gpu_build_relocate(part.gpu, (DevNodeRec *) s->d_nodes, (float *) s->d_tris, (int32_t) part.node_base, (int32_t) part.slot_base);
-         } else {
-            if (!part.nodes.empty())
-               e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, part.nodes.data(), part.nodes.size() * sizeof(DevNodeRec), hipMemcpyHostToDevice);
-            if (e == hipSuccess && !part.tris.empty())
-               e = hipMemcpy((float *) s->d_tris + 12 * part.slot_base, part.tris.data(), part.tris.size() * sizeof(float), hipMemcpyHostToDevice);
-         }
-      }
-      if (e == hipSuccess) e = hipDeviceSynchronize();
+      const hipError_t e = upload_parts(s, parts, node_total, slot_total);
       free_parts();
       if (e != hipSuccess) {
          release_scene(s);
          return hip_fail(e, "hierarchy upload");
       }
-      s->n_node_recs = node_total;
-      s->n_tri_floats = tri_floats;
       s->n_fnrm_floats = all_fnrm.size();
-      int rc;
-      if ((rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s))) {
+      if (int rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s)) {
          release_scene(s);
          return rc;
       }
