@@ -144,3 +144,37 @@ def test_analytic_errors_and_empty(rt):
     o = pair.oscene.render(ocam, ost)
     assert (o["hit_id"] == -1).all() and np.array_equal(cam.hit_id.T, o["hit_id"]) and np.array_equal(cam._rgb_rows, o["rgb"])
     pair.close()
+
+
+def test_tile_shards_and_passes_with_analytic_objects(rt):
+    """The analytic kernels run per queue entry, so tile sharding (multi-GPU) and multi-pass frames must not change a
+    pixel: three ranks' tiles of the Whitted scene merge to the single-rank frame, and a frame of two passes equals
+    the oracle's."""
+    import ctypes as C
+    import torch
+    from helpers import Pair, compare_frames
+    pair = Pair(whitted_objects(rt, False), orientation=(0, 0, 0), fov=35.0, phong=True)
+    W, H = 208, 120
+    cam = rt.Camera(pair.scene, 2, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=11)
+
+    def frame():
+        rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        obj = torch.full((H, W), -9, dtype=torch.int32, device="cuda")
+        w = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        return rt._abi.Frame(rgb.data_ptr(), None, None, obj.data_ptr(), w.data_ptr()), rgb, obj, w
+    f1, rgb1, obj1, w1 = frame()
+    cam.render_device(f1)
+    torch.cuda.synchronize()
+    assert set(obj1.unique().tolist()) == {-1, 0, 1, 2}
+    f3, rgb3, obj3, w3 = frame()
+    for r in range(3):
+        cam.render_device(f3, tile_rank=r, tile_world=3, tile_size=16)
+    torch.cuda.synchronize()
+    assert torch.equal(obj3, obj1) and torch.equal(w3, w1) and torch.equal(rgb3, rgb1)
+    # two passes: 1920 x 1088 x 9 samples > 2^24 slots
+    cam2, ocam, ost = pair.cameras(1920, 1088, ms=9, seed=4)
+    cam2.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=1)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam2._rgb_rows, cam2.hit_id.T, cam2.hit_w.T, o)
+    assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
+    pair.close()
