@@ -190,6 +190,15 @@ def main():
     if world == 1 and tile_world == 1 and args.frames_in_flight > 1:
         pipelined = frames_in_flight(rt, args, mesh, light, cfg, dev, W, H, rays_per_frame)
 
+    # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
+    frame_verified = None
+    if world > 1:
+        rgb1, id1, w1 = torch.zeros_like(rgb), torch.zeros_like(hit_id), torch.zeros_like(hit_w)
+        whole = rt._abi.Frame(rgb1.data_ptr(), None, id1.data_ptr(), None, w1.data_ptr())
+        cam.render_device(whole, stream=stream, tile_rank=0, tile_world=1, tile_size=tiles.DEFAULT_TILE)
+        torch.cuda.synchronize()
+        frame_verified = bool(torch.equal(rgb1, rgb) and torch.equal(id1, hit_id) and torch.equal(w1, hit_w))
+
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_baseline(args, verts, idx, cfg, light)
@@ -209,6 +218,8 @@ def main():
     }
     if pipelined:
         out["pipelined"] = pipelined
+    if frame_verified is not None:
+        out["config"]["gathered_frame_equals_single_gpu_frame"] = frame_verified
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
     print(json.dumps(out))
