@@ -153,7 +153,13 @@ def main():
     lp, ls, lsec, lb, lt, lh = [float(x) for x in local_counts.tolist()]
     own_pixels = float(sharder.my_pix.ge(0).sum().item())
     frame_bytes = BYTES_PER_BOX_TEST * lb + BYTES_PER_TRI_TEST * lt + BYTES_PER_HIT * lh + BYTES_PER_PIXEL * own_pixels
-    kc = kcounts[dom]
+    kc = dict(kcounts[dom])
+    # MODE_FUSED: the primary launch walked the shadow rays too (no shadow launch); their tests belong to it
+    fused = dom == "walk_primary" and "walk_shadow" not in kernels and kcounts["walk_shadow"]["rays"] > 0
+    if fused:
+        for k in ("rays", "box_tests", "tri_tests"):
+            kc[k] += kcounts["walk_shadow"][k]
+        kernels[dom].update(rays=kc["rays"], box_tests=kc["box_tests"], tri_tests=kc["tri_tests"])
     n_launch = max(kernels[dom]["launches_per_frame"], 1.0)
     # SURVEY.md 8(d) per-unit figures x the units one launch of that kernel processes (counted by the kernel itself
     # in the instrumented frame): child boxes tested, triangle slots tested, final hits whose normals are fetched
@@ -174,7 +180,8 @@ def main():
     dom_rays = max(kc["rays"] / n_launch, 1.0)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": {"walk_primary": "walk_kernel<0,MODE_CLOSEST> (primary rays)",
+                "kernel": "walk_kernel<0,MODE_FUSED> (primary rays, each hit's shadow ray walked by the same lane)" if fused else
+                          {"walk_primary": "walk_kernel<0,MODE_CLOSEST> (primary rays)",
                            "walk_shadow": "walk_kernel<0,MODE_SHADOW_ANY> (shadow rays)"}.get(dom, dom),
                 "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "rays_per_launch": dom_rays, "bytes_per_ray": round(algo_bytes / dom_rays, 1),

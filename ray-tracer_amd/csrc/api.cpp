@@ -401,6 +401,7 @@ hipError_t upload_parts(mi355rt_scene *s, std::vector<ScenePart> &parts, size_t 
 // a pass renders at most this many sample slots at once (bounds the scratch: ~104 B per slot,
 // ~204 B with mirrors, 144 B more with a RefractionMaterial)
 constexpr size_t PASS_SLOTS = (size_t) 1 << 24;
+constexpr unsigned long long FUSE_MIN_SLOTS = 3000000ull;   // passes of at least this many samples walk shadow rays inside the primary launch
 
 int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_refraction)
 {
@@ -501,6 +502,12 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    std::memcpy(p.light_emission, st->light_emission, sizeof(p.light_emission));
    std::memcpy(p.light_ambient, st->light_ambient, sizeof(p.light_ambient));
    p.shadow_any_hit = shadow_any_hit_is_exact(s, st) ? 1 : 0;
+   // One launch for primary and shadow rays (walk_kernel MODE_FUSED) is possible when the shadow answer is "any accepted
+   // face" and the primary hit is final once the mesh walk ends (no spheres or planes to compare it with afterwards).
+   // Here: 0 never, 1 for passes long enough to gain from it (run_frame), 2 always.  MI355RT_FUSE_SHADOW=0/1 forces it.
+   const char *fuse_env = getenv("MI355RT_FUSE_SHADOW");
+   const bool can_fuse = p.shadow_any_hit && st->lighting_model == MI355RT_LIGHTING_PHONG && s->n_analytic == 0;
+   p.fused_shadow = !can_fuse || (fuse_env && fuse_env[0] == '0') ? 0 : ((fuse_env && fuse_env[0] == '1') ? 2 : 1);
    p.brdf_dirs = s->d_brdf_dirs;
    p.brdf_weights = s->d_brdf_weights;
    p.n_dirs = s->n_dirs;
@@ -560,19 +567,25 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       s->stats_valid = true;
    }
 
+   const int fuse_policy = p.fused_shadow;
    for (long long m0 = 0; m0 < n_micro; m0 += micro_per_pass) {
       const long long m1 = std::min(n_micro, m0 + micro_per_pass);
       p.micro_begin = (int32_t) m0;
       p.micro_end = (int32_t) m1;
       p.band_cap = (uint32_t) ((((unsigned long long) (m1 - m0) + N_BANDS - 1) / N_BANDS) * slots_per_micro);
       const unsigned long long slots = (unsigned long long) p.band_cap * N_BANDS;   // queue capacity of the pass
+      // Measured on the bench frame and on 1/2, 1/4, 1/8 of it: the fused launch wins on 4 M samples and more (no second
+      // launch draining the chip), ties at 2 M and loses below (a short launch is mostly tail, and shadow rays dealt out
+      // afresh over all waves end sooner than each wave's own).
+      p.fused_shadow = fuse_policy == 2 || (fuse_policy == 1 && slots >= FUSE_MIN_SLOTS) ? 1 : 0;
       HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
       HIP_TRY(timer.run(MI355RT_K_GENERATE, [&] { return launch_generate(p, stream); }));
       int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
       auto next_cursor = [&]() -> int { return CNT_CURSOR0 + 8 * (cursor_set++); };
       const int cw0 = next_cursor();
       HIP_TRY(timer.run(MI355RT_K_WALK_PRIMARY, [&] {
-         return launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cw0, p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, p.diag, stream);
+         return launch_trace(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, cw0, p.band_cap, slots, s->n_cus, p.stats ? 2 : 0, p.diag, stream,
+                             p.fused_shadow ? p.light_origin : nullptr, p.fused_shadow ? p.mat0 : nullptr);
       }));
       if (s->n_analytic) HIP_TRY(timer.run(MI355RT_K_ANALYTIC, [&] {
          return launch_analytic_closest(p.sc, p.rays0, p.hits0, p.hit_obj0, p.counters, CNT_Q0, p.band_cap, slots, s->n_cus, p.stats, stream);
@@ -605,7 +618,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       }
       if (p.lighting_model == MI355RT_LIGHTING_PHONG) {
          const int cw = CNT_CURSOR0 + 8 * (CNT_CURSOR_SETS - 1);
-         HIP_TRY(timer.run(MI355RT_K_WALK_SHADOW, [&] { return launch_shadow(p, cw, slots, s->n_cus, stream); }));
+         if (!p.fused_shadow) HIP_TRY(timer.run(MI355RT_K_WALK_SHADOW, [&] { return launch_shadow(p, cw, slots, s->n_cus, stream); }));
          if (s->n_analytic) HIP_TRY(timer.run(MI355RT_K_ANALYTIC, [&] { return launch_analytic_shadow(p, slots, s->n_cus, stream); }));
          HIP_TRY(timer.run(MI355RT_K_PHONG, [&] { return launch_phong(p, slots, s->n_cus, stream); }));
       }

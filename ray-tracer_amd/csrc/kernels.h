@@ -9,7 +9,8 @@ namespace mi355rt {
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream);
 // stats: 0 none, 1 count boxes / triangles, 2 also count hits (the primary queue)
 hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
-                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, int diag, hipStream_t stream);
+                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, int diag, hipStream_t stream,
+                        const float *fuse_light = nullptr, float *fuse_mat0 = nullptr);   // both set: MODE_FUSED (primary + shadow rays in one launch)
 hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const float *hits, const int32_t *hit_obj, int count_index,
                         float *rays_next, int next_count_index, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long long max_items, int n_cus, hipStream_t stream);

@@ -145,6 +145,7 @@ struct FrameArgs {
    uint64_t rng_seed;
    float light_origin[3], light_emission[3], light_ambient[3];
    int32_t shadow_any_hit;   // host-proven: any accepted hit occludes (see api.cpp)
+   int32_t fused_shadow;     // the primary launch walked the shadow rays too (walk_kernel MODE_FUSED): mat0[].w is already set
    const float *brdf_dirs;      // n_dirs * 3, remapped
    const float *brdf_weights;   // n_materials * n_dirs
    int32_t n_dirs, n_materials;

@@ -341,7 +341,10 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
 // blockIdx % 8 (workgroups b and b + 8 share an XCD, hence an L2) and moves on to the next range
 // when its own is drained.  Queue order follows image order, so each L2 mostly sees one band of the
 // image.  Placement only affects speed: every ray is claimed exactly once whatever runs where.
-enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2 };
+// MODE_FUSED: closest hits for the queue's rays, and each lane whose ray hit something goes straight on to walk that
+// hit's shadow ray (any-hit, see shadow_any_hit_is_exact) before it takes another ray: no shadow queue, no second launch
+// with a tail of its own, and the short shadow walks fill lanes that would otherwise idle until the next refill.
+enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2, MODE_FUSED = 3 };
 
 struct WalkArgs {
    SceneArgs sc;
@@ -401,11 +404,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    // per lane
    // role, owner, pending, k and mirror share one register (the kernel sits at the 80-VGPR step for 6 waves/SIMD)
    struct {
-      unsigned role : 2, owner : 6, pending : 8;
+      unsigned role : 2, owner : 6, pending : 6;
       int k : 7, mirror : 7;   // -1 .. MAX_OBJECTS - 1
       unsigned plain : 1;      // finite origin and 1/direction (and finite node boxes): no NaN can arise in the slab test
-      unsigned unsaved : 1;    // MODE_CLOSEST, ROLE_IDLE: the finished ray's result is still in registers (see "retire" below)
+      unsigned unsaved : 1;    // closest modes, ROLE_IDLE: the finished ray's result is still in registers (see "retire" below)
+      unsigned shadow : 1;     // MODE_FUSED: this lane walks (or helps walk) a shadow ray
    } st;
+   constexpr bool CLOSEST = MODE == MODE_CLOSEST || MODE == MODE_FUSED;   // rays come from the queue; faces wait in `pend`
+   constexpr bool FUSED = MODE == MODE_FUSED;
    static_assert(MAX_OBJECTS <= 64, "k and mirror are 7-bit fields");
    st.role = ROLE_IDLE;
    st.owner = lane;      // the lane whose ray this lane is walking (itself unless ROLE_HELPER)
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    st.k = -1;
    st.plain = 0;
    st.unsaved = 0;
+   st.shadow = 0;
    int cur = STACK_EMPTY;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
@@ -428,7 +435,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    int ob_slot = -1, ob_key = 0, best_slot = -1, best_obj = -1;
    bool occluded = false;
    int s = 0;   // current slot while cur < 0 (cur stays ~first slot of the leaf, which is also the leaf's rank in fold order)
-   unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0;
+   unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0, n_spawn = 0;
+   unsigned n_box_s = 0, n_tri_s = 0;   // MODE_FUSED: tests made for shadow rays
    unsigned d_ray_trips = 0, d_ray_trips_max = 0;
    unsigned d_hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
    unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_lane = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       // only notes the slot; here, once enough lanes hold one (or a lane needs its answer: its walk of the object is
       // over, or it found another face), all of them are worked out together and folded into the lane's best.  The
       // fold does not depend on when it happens (see the tie rule), and slots of one leaf still arrive in slot order.
-      if (MODE == MODE_CLOSEST) {
+      if (CLOSEST) {
          const unsigned long long pm = __ballot(pend >= 0);
          if (pm != 0ull && (resolve_req || exhausted || __popcll(pm) >= a.resolve_min || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
             const float sd = st.k >= 0 ? a.sc.objs[st.k].shadow_distance : 0.0f;
@@ -464,6 +472,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                      ob_slot = slot;
                      ob_key = key;
                      lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
+                     if (FUSED && st.shadow) {   // any accepted face occludes: the walk ends here
+                        sp = bot;
+                        cur = STACK_EMPTY;
+                        s = ~cur;
+                     }
                   }
                }
             }
@@ -501,13 +514,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // object's result, enter the next object or retire the ray
          if (st.role == ROLE_OWNER && cur == STACK_EMPTY && st.pending == 0) {
             if (st.k >= 0 && ob_slot >= 0) {
-               if (MODE == MODE_CLOSEST) {
+               if (CLOSEST && !(FUSED && st.shadow)) {
                   if ((ob_w > eps) && (best_obj < 0 || ob_w < best_w)) {   // Camera.java:208
                      best_w = ob_w;
                      best_slot = ob_slot;
                      best_obj = st.k;
                   }
-               } else if (MODE == MODE_SHADOW_ANY) {
+               } else if (MODE == MODE_SHADOW_ANY || FUSED) {
                   occluded = true;
                } else if (ob_w > eps) {   // RTStatics.java:628-633
                   const float4 *t = tris + 3 * (size_t) ob_slot;
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                }
             }
             int nk = st.k + 1;
-            if (MODE == MODE_CLOSEST && nk == st.mirror) ++nk;
+            if (CLOSEST && nk == st.mirror) ++nk;
             const bool done = (nk >= n_objs) || (MODE != MODE_CLOSEST && occluded);
             if (!done) {
                st.k = nk;
@@ -527,15 +540,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                ob_w = 0.0f;
                ob_key = 0;
                sp = bot = 0;
-               lim2 = (MODE == MODE_CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max) : __builtin_inff();
+               lim2 = (CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max) : __builtin_inff();
                float te;
-               if (STATS) n_box++;
+               if (STATS) (FUSED && st.shadow ? n_box_s : n_box)++;
                if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {
                   cur = ob->root_entry;   // KDTree.getChildIntersection (bounds/KDTree.java:59-65)
                   s = ~cur;
                }
             } else {
-               if (MODE == MODE_CLOSEST) st.unsaved = 1;
+               if (CLOSEST && !(FUSED && st.shadow)) st.unsaved = 1;
                else a.mat0[4 * (size_t) qi + 3] = occluded ? 1.0f : 0.0f;
                st.role = ROLE_IDLE;
             }
@@ -546,13 +559,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // lane at a time cost a fifth of the kernel's instructions.  A finished lane keeps its result in registers
          // instead (nothing touches an idle lane's ray or best-so-far) until the wave is about to hand idle lanes new
          // work -- a refill or a steal -- and then all of them are written in one go.
-         if (MODE == MODE_CLOSEST) {
+         if (CLOSEST) {
             const unsigned long long um = __ballot(st.unsaved != 0);
             if (um != 0ull) {
                const unsigned long long idle_now = __ballot(st.role == ROLE_IDLE);
                const int n_idle = __popcll(idle_now);
                const bool refill_now = !exhausted && (n_idle >= a.refill_min || idle_now == ~0ull);
-               const bool steal_now = exhausted || n_idle >= a.steal_min || a.age_min < (1 << 29);
+               const bool steal_now = exhausted || n_idle >= a.steal_min;
                if ((refill_now || steal_now) && st.unsaved) {
                   float4 h0 = make_float4(0, 0, 0, 0), h1 = make_float4(0, 0, 0, __int_as_float(-1));
                   if (best_obj >= 0) {
@@ -575,6 +588,26 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   hq[1] = h1;
                   a.hit_obj[qi] = best_obj;
                   st.unsaved = 0;
+                  if (FUSED && best_obj >= 0) {
+                     // the lane goes on with this hit's shadow ray (RTStatics.java:619-620, then the Ray ctor;
+                     // RTStatics.offsetPosition): the same arithmetic on the same bits as a shadow launch reading the record
+                     const V3 P = mk3(h0.x, h0.y, h0.z), N = mk3(h1.x, h1.y, h1.z);
+                     make_ray(r, add3(P, scale3(N, eps)), normalize3(normalize3(sub3(light, P))));
+                     st.plain = plain_ray(r) && a.sc.boxes_finite;
+                     st.role = ROLE_OWNER;
+                     st.owner = lane;
+                     st.pending = 0;
+                     st.k = -1;
+                     st.mirror = -1;
+                     st.shadow = 1;
+                     sp = bot = 0;
+                     best_obj = -1;
+                     best_slot = -1;
+                     best_w = 0.0f;
+                     occluded = false;
+                     age = 0;
+                     if (STATS) n_spawn++;
+                  }
                }
             }
          }
@@ -588,7 +621,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             // (what the cursor counts) -> ray (L % spread) * rows + L / spread.  Neighbouring rays (a grazing patch of
             // the surface means long walks for all of them) then land in different waves instead of making one wave
             // the launch's tail.  Shadow rays only: primary rays lose more from the lost coherence than they gain (measured).
-            constexpr unsigned SPREAD = MODE == MODE_CLOSEST ? 1u : (unsigned) WALK_SHADOW_SPREAD;
+            constexpr unsigned SPREAD = CLOSEST ? 1u : (unsigned) WALK_SHADOW_SPREAD;
             unsigned base = 0, rows = 0, count = 0, lo = 0;
             bool got = false;
             while (attempt < N_BANDS) {
@@ -617,7 +650,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                if (my < limit) {
                   qi = my;
                   V3 o, d;
-                  if (MODE == MODE_CLOSEST) {
+                  if (CLOSEST) {
                      const float4 *q = (const float4 *) a.rays + 2 * (size_t) my;
                      const float4 r0 = q[0], r1 = q[1];
                      o = mk3(r0.x, r0.y, r0.z);
@@ -638,6 +671,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   st.owner = lane;
                   st.pending = 0;
                   st.k = -1;
+                  st.shadow = 0;
                   sp = bot = 0;
                   best_obj = -1;
                   best_slot = -1;
@@ -661,17 +695,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // ---- (4) lanes still idle steal work inside the wave: the BOTTOM stack entry (the largest
          // pending subtree) of a busy lane, walked with a copy of that lane's ray.  Which lane walks a
          // subtree cannot change the result: the fold is order independent (see the header comment).
-         const unsigned long long thieves = __ballot(st.role == ROLE_IDLE);
+         const unsigned long long thieves = __ballot(st.role == ROLE_IDLE && !st.unsaved);   // an unsaved lane still holds its ray
          // Before the queue is dry a steal needs steal_min idle lanes (they would rather wait for a refill) -- except,
          // for shadow rays, from a ray that has been walked for age_min trips already: those few long rays are what
          // the launch ends up waiting for, so they get help as soon as a lane is free.
          const bool steal_any = (exhausted && __popcll(thieves) >= a.tail_steal_min) || __popcll(thieves) >= a.steal_min;
-         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || age >= a.age_min));
+         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || ((!FUSED || st.shadow) && age >= a.age_min)));
          if (thieves != 0ull && victims != 0ull) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
             const int v_rank = rank_below(victims), t_rank = rank_below(thieves);
             const bool is_victim = ((victims >> lane) & 1ull) != 0ull && v_rank < n_pairs;
-            const bool is_thief = st.role == ROLE_IDLE && t_rank < n_pairs;
+            const bool is_thief = st.role == ROLE_IDLE && !st.unsaved && t_rank < n_pairs;
             if (is_victim) list[v_rank] = lane;
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the list is written before it is read (one wave, in order)
             const int v = is_thief ? list[t_rank] : lane;
@@ -683,11 +717,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             const float dx = __shfl(r.d.x, v, 64), dy = __shfl(r.d.y, v, 64), dz = __shfl(r.d.z, v, 64);
             const float ix = __shfl(r.inv.x, v, 64), iy = __shfl(r.inv.y, v, 64), iz = __shfl(r.inv.z, v, 64);
             const int v_age = __shfl(age, v, 64);
+            const int v_shadow = FUSED ? __shfl((int) st.shadow, v, 64) : 0;
             if (is_victim) ++bot;
             if (is_thief) {
                st.role = ROLE_HELPER;
                st.owner = v_owner;
                st.k = v_k;
+               st.shadow = (unsigned) v_shadow;
                lim2 = v_lim2;
                r.o = mk3(ox, oy, oz);
                r.d = mk3(dx, dy, dz);
@@ -762,7 +798,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          }
          float tl = 0.0f, tr = 0.0f;
          bool lok = false, rok = false;
-         if (STATS) n_box += (nd.x != LINK_NONE ? 1u : 0u) + (nd.y != LINK_NONE ? 1u : 0u);
+         if (STATS) (FUSED && st.shadow ? n_box_s : n_box) += (nd.x != LINK_NONE ? 1u : 0u) + (nd.y != LINK_NONE ? 1u : 0u);
          if (st.plain) {
             // Both children at once in packed f32 (the record interleaves them).  With every operand finite no NaN can
             // arise, and RTStatics.aabbIntersection (RTStatics.java:102-158) reduces to its textbook form: per axis
@@ -825,9 +861,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          const int n_left = __float_as_int(q[1].w);
          bool stop = n_left <= LEAF_BATCH;
          bool advance = true;
-         if (MODE == MODE_CLOSEST) {
+         if (CLOSEST) {
             static_assert(LEAF_BATCH == 2, "the pending-face word holds one slot and a flag for the next");
-            if (STATS) n_tri += n_left > 1 ? 2u : 1u;
+            if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += n_left > 1 ? 2u : 1u;
             const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
             const bool m1 = n_left > 1 && tri_meets(q[3], q[4], q[5], r, eps);
             if (m0 || m1) {
@@ -837,7 +873,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   advance = false;   // one waits already: it is worked out first, then this pair of faces is tested again
                }
             }
-            resolve_req = __ballot(!advance) != 0ull;
+            // a shadow ray's first face is worked out at once: if it is accepted the walk is over
+            resolve_req = __ballot(!advance || (FUSED && st.shadow && pend >= 0)) != 0ull;
          } else {
 #pragma unroll
          for (int j = 0; j < LEAF_BATCH; j++) {
@@ -876,14 +913,20 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    }
 
    if (STATS) {
-      add_stat(a.counters, ST_BOX, n_box);
-      add_stat(a.counters, ST_TRI, n_tri);
-      if (MODE != MODE_CLOSEST) add_stat(a.counters, ST_SHADOW, n_ray);
+      add_stat(a.counters, ST_BOX, n_box + n_box_s);
+      add_stat(a.counters, ST_TRI, n_tri + n_tri_s);
+      if (!CLOSEST) add_stat(a.counters, ST_SHADOW, n_ray);
+      if (FUSED) add_stat(a.counters, ST_SHADOW, n_spawn);
       add_stat(a.counters, ST_HITS, a.stats == 2 ? n_hit : 0u);
-      const int kind = MODE != MODE_CLOSEST ? 2 : (a.stats == 2 ? 0 : 1);
+      const int kind = !CLOSEST ? 2 : (a.stats == 2 ? 0 : 1);
       add_stat(a.counters, ST_KIND_RAYS + kind, n_ray);
       add_stat(a.counters, ST_KIND_BOX + kind, n_box);
       add_stat(a.counters, ST_KIND_TRI + kind, n_tri);
+      if (FUSED) {   // the shadow rays' share is booked as the shadow launch's would be
+         add_stat(a.counters, ST_KIND_RAYS + 2, n_spawn);
+         add_stat(a.counters, ST_KIND_BOX + 2, n_box_s);
+         add_stat(a.counters, ST_KIND_TRI + 2, n_tri_s);
+      }
       if (STATS > 1) {
          add_stat(a.counters, ST_NODE_LANE, d_node_lane);
          add_stat(a.counters, ST_NODE_WAVE, d_node_wave);
@@ -1053,7 +1096,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
       }
       if (have_mat) {
          if (p.lighting_model == 1) {
-            ((float4 *) p.mat0)[path] = make_float4(mat[0], mat[1], mat[2], 0.0f);
+            if (p.fused_shadow) {   // .w holds the shadow ray's answer already (MODE_FUSED)
+               float *m3 = p.mat0 + 4 * (size_t) path;
+               m3[0] = mat[0];
+               m3[1] = mat[1];
+               m3[2] = mat[2];
+            } else {
+               ((float4 *) p.mat0)[path] = make_float4(mat[0], mat[1], mat[2], 0.0f);
+            }
             push_shadow = true;
          } else {
             ((float4 *) p.samples)[slot] = make_float4(mat[0], mat[1], mat[2], 0.0f);   // LightingModel.java:13-15
@@ -1310,7 +1360,8 @@ hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, hipStr
 }   // namespace
 
 hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int32_t *hit_obj, uint32_t *counters, int count_index,
-                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, int diag, hipStream_t stream)
+                        int cursor_index, unsigned band_cap, unsigned long long max_items, int n_cus, int stats, int diag, hipStream_t stream,
+                        const float *fuse_light, float *fuse_mat0)
 {
    WalkArgs a;
    a.sc = sc;
@@ -1318,9 +1369,9 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.hits = hits;
    a.hit_obj = hit_obj;
    a.hits0 = nullptr;
-   a.mat0 = nullptr;
+   a.mat0 = fuse_mat0;
    a.shadow = nullptr;
-   a.light[0] = a.light[1] = a.light[2] = 0.0f;
+   for (int c = 0; c < 3; c++) a.light[c] = fuse_light ? fuse_light[c] : 0.0f;
    a.counters = counters;
    a.count_index = count_index;
    a.cursor_index = cursor_index;
@@ -1331,8 +1382,10 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    a.resolve_min = tunable("MI355RT_RESOLVE_MIN", 12);
-   a.age_min = tunable("MI355RT_AGE_MIN_CLOSEST", 1 << 30);
-   return launch_walk<MODE_CLOSEST>(a, persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, 6)), stats ? (diag ? 2 : 1) : 0, stream);
+   a.age_min = tunable(fuse_light ? "MI355RT_AGE_MIN_FUSED" : "MI355RT_AGE_MIN_CLOSEST", 1 << 30);
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, 6));
+   if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
+   return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)

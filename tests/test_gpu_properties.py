@@ -95,11 +95,14 @@ def test_multi_pass_frame(rt, orc):
     scene.close()
 
 
-def test_determinism_and_counter_identities(rt):
+@pytest.mark.parametrize("fused", [True, False])
+def test_determinism_and_counter_identities(rt, monkeypatch, fused):
     """Two renders are bit-identical (whatever wave walked which ray or stole which subtree), and the
     counters obey: primary = W*H*spp, shadow = hits (one shadow ray per hit sample, RTStatics.java:617),
-    per-kernel counts add up."""
+    per-kernel counts add up.  Both pipelines: shadow rays walked inside the primary launch (the default
+    when any accepted face occludes) and in a launch of their own."""
     import torch
+    monkeypatch.setenv("MI355RT_FUSE_SHADOW", "1" if fused else "0")
     scene, _, _, _ = _scene(rt, 100000)
     W, H, ms = 320, 200, 4
     cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=11)
@@ -120,10 +123,39 @@ def test_determinism_and_counter_identities(rt):
     assert kp["walk_shadow"]["rays"] == st["shadow_rays"]
     assert kp["walk_primary"]["tri_tests"] + kp["walk_shadow"]["tri_tests"] == st["tri_tests"]
     for name in ("generate", "walk_primary", "shade", "walk_shadow", "phong", "resolve"):
-        assert kp[name]["launches"] == 1 and kp[name]["ms"] > 0.0
+        if name == "walk_shadow" and fused:
+            assert kp[name]["launches"] == 0
+        else:
+            assert kp[name]["launches"] == 1 and kp[name]["ms"] > 0.0
     assert kp["walk_secondary"]["launches"] == 0
     assert cam.kernel_profile()["walk_primary"]["launches"] == 0      # reset
     scene.close()
+
+
+def test_shadow_rays_inside_the_primary_launch_equal_the_separate_launch(rt, monkeypatch):
+    """MODE_FUSED (each lane walks its hit's shadow ray before it takes another primary ray) gives the frame the
+    two-launch pipeline gives, bit for bit -- on a scene with two meshes, one of them a mirror (the shadow ray leaves
+    the PRIMARY hit whatever the bounces find), and on the BASELINE Dragon frame."""
+    import torch
+    v2, i2 = rt.meshgen.stanford_standin("bunny", 4000)
+    v2 = (v2 * 0.6 + np.array([0.12, 0.05, 0.0], dtype=np.float32)).astype(np.float32)
+    mirror = rt.TriangleMesh((v2, i2), rt.ReflectionMaterial((0.8, 0.8, 0.8)), True)
+    for faces, extra, W, H, ms in ((20000, (mirror,), 320, 240, 2), (None, (), 1920, 1080, 4)):
+        scene, _, _, _ = _scene(rt, faces, extra=extra)
+        cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=5)
+        frames = {}
+        for fused in ("1", "0"):
+            monkeypatch.setenv("MI355RT_FUSE_SHADOW", fused)
+            f, rgb, hid, hw = _device_frame(rt, cam)
+            cam.render_device(f, collect_stats=True, collect_times=True)
+            torch.cuda.synchronize()
+            kp = cam.kernel_profile(reset=True)
+            assert kp["walk_shadow"]["launches"] == (0 if fused == "1" else 1)
+            assert kp["walk_shadow"]["rays"] == cam.frame_stats()["shadow_rays"] > 0
+            frames[fused] = (rgb, hid, hw)
+        for x, y in zip(frames["1"], frames["0"]):
+            assert torch.equal(x, y)
+        scene.close()
 
 
 def test_mirror_bounces_between_two_mirrors(rt, orc):
