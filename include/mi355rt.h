@@ -203,6 +203,14 @@ int mi355rt_camera_setup(const mi355rt_scene *scene, const float orientation_deg
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
                    int32_t *hit_id_out, float *hit_w_out);
 
+/* Page-locked host memory for the buffers mi355rt_render writes to: its device-to-host copies then run at PCIe
+ * speed instead of through the runtime's staging buffers (figures in DESIGN.md section 5).  No counterpart in the
+ * reference, which has no device: it is for hosts that keep one output buffer per camera, as Camera.pixels is one
+ * array (Camera.java:38) -- a Java shim wraps the pointer once with NewDirectByteBuffer.  Ordinary memory works
+ * too, only slower.  Free with mi355rt_host_free, not free(). */
+int mi355rt_host_alloc(uint64_t bytes, void **ptr_out);
+int mi355rt_host_free(void *ptr);
+
 /* Same frame, outputs left in device memory (pointers in `frame` are device pointers on the
  * scene's device).  Asynchronous on `hip_stream` (a hipStream_t, NULL = the null stream); the
  * caller synchronises.  With tile_world > 1 only this rank's tiles are written. */

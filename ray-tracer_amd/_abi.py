@@ -97,6 +97,8 @@ PROTOTYPES = {
     "mi355rt_camera_setup": (C.c_int, [C.c_void_p, c_float_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                        C.POINTER(CameraDesc)]),
     "mi355rt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), c_float_p, c_int32_p, c_float_p]),
+    "mi355rt_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mi355rt_host_free": (C.c_int, [C.c_void_p]),
     "mi355rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
     "mi355rt_frame_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mi355rt_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile), C.c_int]),

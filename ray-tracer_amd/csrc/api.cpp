@@ -1038,6 +1038,21 @@ int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355r
    return MI355RT_OK;
 }
 
+int mi355rt_host_alloc(uint64_t bytes, void **ptr_out)
+{
+   if (!ptr_out || !bytes) return fail(MI355RT_E_ARG, "null pointer or zero size");
+   *ptr_out = nullptr;
+   HIP_TRY(hipHostMalloc(ptr_out, (size_t) bytes, hipHostMallocDefault));
+   return MI355RT_OK;
+}
+
+int mi355rt_host_free(void *ptr)
+{
+   if (!ptr) return MI355RT_OK;
+   HIP_TRY(hipHostFree(ptr));
+   return MI355RT_OK;
+}
+
 int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
 {
    if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");

@@ -390,6 +390,8 @@ class Camera:
         self.screenWidth = int(screenWidth)
         self.screenHeight = int(screenHeight)
         self.rng_seed = int(rng_seed)
+        self._pinned = None
+        self._pinned_ptr = None
         self.listeners = []
         self._lib = _abi.load()
         self._cam = _abi.CameraDesc()
@@ -429,11 +431,40 @@ class Camera:
     def addActionListener(self, listener):
         self.listeners.append(listener)
 
+    def pinOutput(self, on=True):
+        """Keep ONE page-locked set of output arrays for this camera, as Camera.pixels is one array (Camera.java:38):
+        createImage() then overwrites them in place, and the copies back from the device run at PCIe speed."""
+        if self._pinned_ptr:
+            # arrays handed out earlier are views of this memory: after this call they must not be used
+            self._pinned = None
+            _abi.check(self._lib.mi355rt_host_free(self._pinned_ptr))
+            self._pinned_ptr = None
+        if on:
+            W, H = self.screenWidth, self.screenHeight
+            n = W * H
+            ptr = C.c_void_p()
+            _abi.check(self._lib.mi355rt_host_alloc(n * 20, C.byref(ptr)))
+            self._pinned_ptr = ptr
+            base = (C.c_uint8 * (n * 20)).from_address(ptr.value)
+            self._pinned = (np.frombuffer(base, dtype=np.float32, count=n * 3).reshape(H, W, 3),
+                            np.frombuffer(base, dtype=np.int32, count=n, offset=n * 12).reshape(H, W),
+                            np.frombuffer(base, dtype=np.float32, count=n, offset=n * 16).reshape(H, W))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_pinned_ptr", None):
+                self.pinOutput(False)
+        except Exception:
+            pass
+
     def createImage(self):
         W, H = self.screenWidth, self.screenHeight
-        rgb = np.empty((H, W, 3), dtype=np.float32)
-        hid = np.empty((H, W), dtype=np.int32)
-        hw = np.empty((H, W), dtype=np.float32)
+        if self._pinned:
+            rgb, hid, hw = self._pinned
+        else:
+            rgb = np.empty((H, W, 3), dtype=np.float32)
+            hid = np.empty((H, W), dtype=np.int32)
+            hw = np.empty((H, W), dtype=np.float32)
         st = self.settings()
         _abi.check(self._lib.mi355rt_render(self.scene._handle, C.byref(self._cam), C.byref(st), _fp(rgb), _ip(hid), _fp(hw)))
         self._rgb_rows = rgb

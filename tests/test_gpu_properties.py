@@ -158,6 +158,29 @@ def test_shadow_rays_inside_the_primary_launch_equal_the_separate_launch(rt, mon
         scene.close()
 
 
+def test_pinned_output_buffers_give_the_same_frame(rt):
+    """mi355rt_host_alloc: createImage() into one page-locked set of arrays (Camera.pinOutput) returns the frame it
+    returns into fresh pageable arrays, and keeps writing into the same arrays."""
+    scene, _, _, _ = _scene(rt, 20000)
+    cam = rt.Camera(scene, 2, 1, rt.RTStatics.NEAR_PLANE, 320, 200, rng_seed=9)
+    cam.createImage()
+    ref = (cam._rgb_rows.copy(), cam.hit_id.copy(), cam.hit_w.copy())
+    cam.pinOutput(True)
+    cam.createImage()
+    first = cam._rgb_rows
+    assert np.array_equal(first, ref[0]) and np.array_equal(cam.hit_id, ref[1]) and np.array_equal(cam.hit_w, ref[2])
+    first.fill(-7.0)
+    cam.createImage()
+    assert cam._rgb_rows is first and np.array_equal(first, ref[0])
+    del first
+    cam.pinOutput(False)
+    cam.createImage()
+    assert np.array_equal(cam._rgb_rows, ref[0])
+    with pytest.raises(rt._abi.Mi355rtError):
+        rt._abi.check(rt._abi.load().mi355rt_host_alloc(0, C.byref(C.c_void_p())))
+    scene.close()
+
+
 def test_mirror_bounces_between_two_mirrors(rt, orc):
     """Two facing mirrors: paths bounce until max_mirror_bounces cuts them (the reference would recurse
     without bound, bounds/KDTree.java:77-80; the oracle carries the same guard)."""
