@@ -330,6 +330,9 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
 //   MODE_SHADOW      RTStatics.shadowIntersects (RTStatics.java:617-639) for the paths of the
 //                    shadow list: per object the closest accepted hit, then the before-the-light test
 //   MODE_SHADOW_ANY  the same where the host proved that any accepted hit occludes (api.cpp)
+//   MODE_FUSED       MODE_CLOSEST, and each lane whose ray hit something goes straight on to walk that hit's
+//                    shadow ray (as MODE_SHADOW_ANY would) before it takes another ray: no shadow queue pass,
+//                    no second persistent launch with a tail of its own (long passes only: api.cpp)
 //
 // Persistent wave64s.  A LANE that has finished its ray takes the next one from the queue without
 // waiting for the other 63 (rays differ several-fold in length; batch-at-a-time left 5 of 6 lanes
@@ -341,9 +344,6 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
 // blockIdx % 8 (workgroups b and b + 8 share an XCD, hence an L2) and moves on to the next range
 // when its own is drained.  Queue order follows image order, so each L2 mostly sees one band of the
 // image.  Placement only affects speed: every ray is claimed exactly once whatever runs where.
-// MODE_FUSED: closest hits for the queue's rays, and each lane whose ray hit something goes straight on to walk that
-// hit's shadow ray (any-hit, see shadow_any_hit_is_exact) before it takes another ray: no shadow queue, no second launch
-// with a tail of its own, and the short shadow walks fill lanes that would otherwise idle until the next refill.
 enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2, MODE_FUSED = 3 };
 
 struct WalkArgs {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    int attempt = 0;
    bool exhausted = false;
    // per lane
-   // role, owner, pending, k and mirror share one register (the kernel sits at the 80-VGPR step for 6 waves/SIMD)
+   // the small per-lane fields share one register (the kernel sits at the 80-VGPR step for 6 waves/SIMD)
    struct {
       unsigned role : 2, owner : 6, pending : 6;
       int k : 7, mirror : 7;   // -1 .. MAX_OBJECTS - 1
