@@ -578,6 +578,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       // launch draining the chip), ties at 2 M and loses below (a short launch is mostly tail, and shadow rays dealt out
       // afresh over all waves end sooner than each wave's own).
       p.fused_shadow = fuse_policy == 2 || (fuse_policy == 1 && slots >= FUSE_MIN_SLOTS) ? 1 : 0;
+      p.phong_in_shade = p.fused_shadow && !s->has_mirror && !s->has_refraction ? 1 : 0;
       HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
       HIP_TRY(timer.run(MI355RT_K_GENERATE, [&] { return launch_generate(p, stream); }));
       int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
@@ -620,7 +621,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
          const int cw = CNT_CURSOR0 + 8 * (CNT_CURSOR_SETS - 1);
          if (!p.fused_shadow) HIP_TRY(timer.run(MI355RT_K_WALK_SHADOW, [&] { return launch_shadow(p, cw, slots, s->n_cus, stream); }));
          if (s->n_analytic) HIP_TRY(timer.run(MI355RT_K_ANALYTIC, [&] { return launch_analytic_shadow(p, slots, s->n_cus, stream); }));
-         HIP_TRY(timer.run(MI355RT_K_PHONG, [&] { return launch_phong(p, slots, s->n_cus, stream); }));
+         if (!p.phong_in_shade) HIP_TRY(timer.run(MI355RT_K_PHONG, [&] { return launch_phong(p, slots, s->n_cus, stream); }));
       }
       HIP_TRY(timer.run(MI355RT_K_RESOLVE, [&] { return launch_resolve(p, stream); }));
       if (p.stats) {

@@ -1095,7 +1095,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
          }
       }
       if (have_mat) {
-         if (p.lighting_model == 1) {
+         if (LEVEL == 0 && p.phong_in_shade) {
+            // the shadow ray's answer is known already (MODE_FUSED) and the material colour is final: PhongLightingModel
+            // right here, with the values phong_kernel would read back
+            const DevMaterial &m0 = p.sc.objs[obj].mat;
+            float out[3];
+            phong_combine(mat, m0.diffuse, m0.specular, m0.shininess, p.light_emission, p.light_ambient,
+                          mk3(p.light_origin[0], p.light_origin[1], p.light_origin[2]), mk3(h0.x, h0.y, h0.z), mk3(h1.x, h1.y, h1.z),
+                          mk3(r1.x, r1.y, r1.z), p.mat0[4 * (size_t) path + 3] != 0.0f, out);
+            ((float4 *) p.samples)[slot] = make_float4(out[0], out[1], out[2], 0.0f);
+         } else if (p.lighting_model == 1) {
             if (p.fused_shadow) {   // .w holds the shadow ray's answer already (MODE_FUSED)
                float *m3 = p.mat0 + 4 * (size_t) path;
                m3[0] = mat[0];
