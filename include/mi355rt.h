@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 2   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials */
+#define MI355RT_ABI_VERSION 3   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free */
 
 enum {
    MI355RT_OK = 0,
