@@ -479,6 +479,7 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.sc.near_plane = st->near_plane;
    p.sc.far_plane = st->far_plane;
    p.sc.scene_abs_max = s->abs_max;
+   p.sc.max_normal_len = s->max_normal_len;
    p.sc.ext = s->d_ext;
    p.sc.n_analytic = s->n_analytic;
    p.sc.boxes_finite = s->boxes_finite ? 1 : 0;
@@ -1189,6 +1190,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
    a.sc.near_plane = settings->near_plane;
    a.sc.far_plane = settings->far_plane;
    a.sc.scene_abs_max = scene->abs_max;
+   a.sc.max_normal_len = scene->max_normal_len;
    a.sc.ext = scene->d_ext;
    a.sc.n_analytic = scene->n_analytic;
    a.sc.boxes_finite = scene->boxes_finite ? 1 : 0;

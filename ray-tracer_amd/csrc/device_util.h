@@ -125,6 +125,26 @@ __device__ __forceinline__ float prune_limit2(const Ray &r, float w, float scene
    return lim * lim;
 }
 
+// How far a shadow ray has to look (MODE_SHADOW, the reference-exact form).  RTStatics.shadowIntersects accepts an
+// object's closest hit only if w < distance(hit point, light) + EPSILON (RTStatics.java:628-633) -- the distance from
+// the HIT to the light, not from the origin.  The origin is the shaded point P0 moved by N * EPSILON (|N| <= max_n),
+// the direction points from P0 to the light, so a hit at distance t along the ray lies within e = max_n * EPSILON of
+// the segment P0 -> light, and distance(hit, light) <= e + |t - D0| with D0 = |light - P0| <= D + e, D = |light - o|.
+// For t <= D0 the test needs t < (D + 2 e + EPSILON) / 2; for t > D0 it needs D0 < e + EPSILON, excluded below.  So
+// no face farther than W = (D + 2 e + EPSILON) / 2 (taken with 0.1 % on top, and prune_limit2's own margin) can
+// occlude, and boxes beyond it are pruned exactly as boxes beyond a found hit are.  Returns the squared limit,
+// +inf when the bound does not apply (light within a few EPSILON of the surface, non-finite data).
+__device__ __forceinline__ float shadow_reach2(const Ray &r, V3 light, float eps, float max_n, float scene_abs_max)
+{
+   const float D = distance3(r.o, light);
+   const float e = max_n * eps;
+   if (!(D > 4.0f * (e + eps))) return __builtin_inff();
+#ifndef SHADOW_REACH_FACTOR
+#define SHADOW_REACH_FACTOR 0.5f   // a test build with a smaller factor must fail the exact-shadow parity test
+#endif
+   return prune_limit2(r, (D + 2.0f * e + eps) * SHADOW_REACH_FACTOR * 1.001f, scene_abs_max);
+}
+
 // Triangle.intersectsTriangle (sceneObjects/Triangle.java:85-133) on one leaf slot.
 // Returns false where the reference returns null; otherwise the barycentrics, the interpolated
 // point and its distance from the origin (returnValue[6]).

@@ -107,6 +107,7 @@ struct SceneArgs {
    int32_t n_objs;
    float epsilon, near_plane, far_plane;
    float scene_abs_max;   // max |coordinate| of the scene bounds (prune margin)
+   float max_normal_len;  // longest shading normal of the scene (bounds the shadow-ray origin offset); NaN if unknown
    const DevObjectExt *ext;   // [n_objs]
    int32_t n_analytic;        // spheres + planes among the objects
    int32_t boxes_finite;      // every node box is finite: rays with finite origin and 1/direction may take the packed slab test

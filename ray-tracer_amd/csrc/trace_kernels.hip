@@ -540,7 +540,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                ob_w = 0.0f;
                ob_key = 0;
                sp = bot = 0;
-               lim2 = (CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max) : __builtin_inff();
+               lim2 = (CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max)
+                      : (MODE == MODE_SHADOW ? shadow_reach2(r, light, eps, a.sc.max_normal_len, abs_max) : __builtin_inff());
                float te;
                if (STATS) (FUSED && st.shadow ? n_box_s : n_box)++;
                if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {

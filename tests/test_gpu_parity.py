@@ -120,6 +120,40 @@ def test_triangle_soup(rt):
     pair.close()
 
 
+@pytest.mark.parametrize("light_origin", [(0.0, 0.0, 0.0), (0.1, 0.12, -0.05), (0.0, 0.4, 0.4), (0.02, 0.151, 0.0)])
+def test_exact_shadows_with_the_light_inside_the_scene(rt, light_origin):
+    """With the light inside (or just outside) the scene's box the any-hit shortcut cannot be proven and the shadow
+    rays run the reference-exact form: per object the closest accepted hit, which occludes only if it is nearer to the
+    ray's origin than to the light (RTStatics.java:628-633).  The walker looks no farther than half the way to the
+    light plus the origin offset (shadow_reach2); a soup of triangles puts faces before and beyond that distance on
+    most shadow rays, and every pixel's radiance must still match the oracle."""
+    from helpers import Pair
+    v, i = rt.meshgen.soup(20000, span=0.3, tri_size=0.03, seed=12)
+    fv, fi = rt.meshgen.quad(-0.16, 0.5)
+    light = dict(origin=light_origin, emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
+    pair = Pair([(v, i, None, rt.ColorInformation((0.9, 0.9, 0.9))), (fv, fi, None, rt.ColorInformation((0.8, 0.3, 0.2)))],
+                fov=23.0, light=light)
+    hit_frac = _check(pair, 112, 112, ms=2, seed=8)
+    assert hit_frac > 0.1
+    pair.close()
+
+
+@pytest.mark.parametrize("light_origin", [(0.0, 260.0, 0.0), (120.0, 120.0, 150.0)])
+def test_exact_shadows_large_epsilon(rt, light_origin):
+    """The same at EPSILON = 1e-3 (span 400), where the shadow ray's origin offset N * EPSILON is not negligible
+    (synthesised normals are not unit length): a light between two blobs, and one beside them."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(4000, span=400.0, seed=6)
+    v2, i2 = rt.meshgen.blob(2000, span=150.0, seed=2)
+    v2 = (v2 + np.float32([40.0, 330.0, 0.0])).astype(np.float32)
+    light = dict(origin=light_origin, emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
+    pair = Pair([(v, i, None, rt.ColorInformation((1, 1, 1))), (v2, i2, None, rt.ColorInformation((0.8, 0.3, 0.2)))],
+                fov=14.0, light=light)
+    assert np.float32(pair.eps) == np.float32(1e-3)
+    _check(pair, 96, 96, ms=2, seed=3)
+    pair.close()
+
+
 def test_trace_rays_arbitrary(rt):
     """Rays from inside and behind the mesh (hits behind the origin are legal, Triangle.java has no t>0 test),
     axis-aligned directions with +0.0 / -0.0 components."""
