@@ -1,0 +1,56 @@
+"""Randomised GPU-vs-oracle frames: random meshes, materials, lights inside and outside the scene, both shadow
+pipelines.  Used by test_gpu_fuzz.py (a seeded subset) and tools/fuzz_parity.py (as many as asked for)."""
+import os
+
+import numpy as np
+
+from helpers import Pair, compare_frames, synthetic_brdf_tables
+
+
+def random_case(rt, seed):
+    """Builds, renders on both sides and compares one random scene.  Returns (ok, one-line description)."""
+    rs = np.random.RandomState(1000 + seed)
+    scale = float(rs.choice([0.2, 3.0, 400.0]))   # 400: EPSILON = 1e-3 (Scene.java:36)
+    objs = []
+    for k in range(int(rs.randint(1, 4))):
+        if rs.rand() < 0.7:
+            v, i = rt.meshgen.blob(int(rs.randint(300, 5000)), span=scale * rs.uniform(0.3, 1.0), seed=int(rs.randint(1 << 20)),
+                                   stretch=tuple(rs.uniform(0.5, 1.0, 3)))
+        else:
+            v, i = rt.meshgen.soup(int(rs.randint(1000, 6000)), span=scale * rs.uniform(0.5, 1.0), tri_size=rs.uniform(0.02, 0.08),
+                                   seed=int(rs.randint(1 << 20)))
+        v = (v + (rs.uniform(-0.4, 0.4, 3) * scale).astype(np.float32)).astype(np.float32)
+        m = rs.rand()
+        color = tuple(rs.uniform(0.2, 1.0, 3))
+        mat = rt.ReflectionMaterial(color) if m < 0.25 else rt.BRDFMaterial(int(rs.randint(0, 8)), color) if m < 0.45 else rt.ColorInformation(color)
+        objs.append((v, i, None, mat))
+    kind = int(rs.randint(0, 3))   # the reference's far light / a light inside the scene / one around it
+    lo = (0.0, 100.0, 100.0) if kind == 0 else tuple(rs.uniform(-0.5, 0.5, 3) * scale) if kind == 1 else tuple(rs.uniform(-1.5, 1.5, 3) * scale)
+    light = dict(origin=lo, emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
+    fuse = str(rs.choice(["0", "1", ""]))
+    saved = os.environ.get("MI355RT_FUSE_SHADOW")
+    if fuse:
+        os.environ["MI355RT_FUSE_SHADOW"] = fuse
+    else:
+        os.environ.pop("MI355RT_FUSE_SHADOW", None)
+    try:
+        pair = Pair(objs, orientation=tuple(rs.uniform(-40, 40, 3)), fov=float(rs.uniform(10, 30)), phong=bool(rs.rand() < 0.85),
+                    light=light, brdf_tables=synthetic_brdf_tables(), use_kdtree=bool(rs.rand() < 0.9))
+        W, H, ms = int(rs.randint(40, 120)), int(rs.randint(40, 120)), int(rs.randint(1, 4))
+        cam, ocam, ost = pair.cameras(W, H, ms=ms, brdf_samples=int(rs.randint(1, 3)), seed=seed)
+        cam.createImage()
+        o = dict(pair.oscene.render(ocam, ost, n_threads=8))
+        g = np.nan_to_num(cam._rgb_rows, nan=-1.0)   # a NaN-scrubbed pixel must be one on both sides
+        o["rgb"] = np.nan_to_num(o["rgb"], nan=-1.0)
+        ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o)
+        ok = ids_equal and w_equal and max_rel <= 1e-3
+        desc = "seed %d scale %g objs %d light %d fuse %r %dx%dx%d hits %.2f: %s (ids %s w %s rel %.2e diff %d)" % (
+            seed, scale, len(objs), kind, fuse, W, H, ms, float((o["hit_id"] >= 0).mean()), "ok" if ok else "MISMATCH", ids_equal,
+            w_equal, max_rel, n_diff)
+        pair.close()
+    finally:
+        if saved is None:
+            os.environ.pop("MI355RT_FUSE_SHADOW", None)
+        else:
+            os.environ["MI355RT_FUSE_SHADOW"] = saved
+    return ok, desc
