@@ -54,3 +54,55 @@ def random_case(rt, seed):
         else:
             os.environ["MI355RT_FUSE_SHADOW"] = saved
     return ok, desc
+
+
+def random_analytic_case(rt, seed):
+    """The same with the analytic objects of the reference's Whitted / Cornell scenes: planes, spheres, an optional mesh;
+    plain / mirror / refraction / checkerboard / BRDF materials (bounce chains through glass and mirrors)."""
+    rs = np.random.RandomState(5000 + seed)
+
+    def material():
+        m = rs.rand()
+        color = tuple(rs.uniform(0.1, 1.0, 3))
+        if m < 0.2:
+            return rt.ReflectionMaterial(color)
+        if m < 0.4:
+            return rt.RefractionMaterial(color, float(rs.choice([rt.RefractionMaterial.INDEX_OF_GLASS, 1.1, 1.33])))
+        if m < 0.55:
+            return rt.CheckerboardMaterial(color, tuple(rs.uniform(0.1, 1.0, 3)), *[float(x) for x in rs.uniform(2.0, 12.0, 3)])
+        if m < 0.7:
+            return rt.BRDFMaterial(int(rs.randint(0, 8)), color)
+        return rt.ColorInformation(color)
+
+    objs = []
+    h = float(rs.uniform(8.0, 20.0))
+    e = float(rs.uniform(30.0, 60.0))
+    if rs.rand() < 0.8:   # floor
+        objs.append(rt.Plane([(-e, -h, -e), (-e, -h, e), (e, -h, e), (e, -h, -e)], material()))
+    if rs.rand() < 0.5:   # back wall
+        objs.append(rt.Plane([(-e, -h, -e), (e, -h, -e), (e, e, -e), (-e, e, -e)], material()))
+    if rs.rand() < 0.3:   # tilted plane, as the Whitted scene's
+        objs.append(rt.Plane([(-e, 0.0, -2 * e), (-e, -h * 2, e / 2), (e, -h * 2, e / 2), (e, 0.0, -2 * e)], material()))
+    for k in range(int(rs.randint(1, 5))):
+        objs.append(rt.Sphere(float(rs.uniform(1.5, 6.0)), tuple(float(x) for x in rs.uniform(-12.0, 12.0, 3)), material()))
+    if rs.rand() < 0.4:
+        v, i = rt.meshgen.blob(int(rs.randint(300, 3000)), span=float(rs.uniform(6.0, 14.0)), seed=int(rs.randint(1 << 20)))
+        v = (v + rs.uniform(-10.0, 10.0, 3).astype(np.float32)).astype(np.float32)
+        objs.append((v, i, None, material()))
+    lo = (0.0, 100.0, 100.0) if rs.rand() < 0.5 else tuple(float(x) for x in rs.uniform(-40.0, 40.0, 3))
+    light = dict(origin=lo, emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
+    pair = Pair(objs, orientation=tuple(rs.uniform(-30, 30, 3)), fov=float(rs.uniform(15, 40)), phong=bool(rs.rand() < 0.8),
+                light=light, brdf_tables=synthetic_brdf_tables())
+    W, H, ms = int(rs.randint(40, 110)), int(rs.randint(40, 110)), int(rs.randint(1, 3))
+    cam, ocam, ost = pair.cameras(W, H, ms=ms, brdf_samples=int(rs.randint(1, 3)), seed=seed)
+    cam.createImage()
+    o = dict(pair.oscene.render(ocam, ost, n_threads=8))
+    g = np.nan_to_num(cam._rgb_rows, nan=-1.0)
+    o["rgb"] = np.nan_to_num(o["rgb"], nan=-1.0)
+    # hit ids of analytic objects are -1 on both sides (no faces): the object index is compared through w and radiance
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o)
+    ok = ids_equal and w_equal and max_rel <= 1e-3
+    desc = "analytic seed %d objs %d %dx%dx%d hits(w>0) %.2f: %s (ids %s w %s rel %.2e diff %d)" % (
+        seed, len(objs), W, H, ms, float((o["hit_w"] > 0).mean()), "ok" if ok else "MISMATCH", ids_equal, w_equal, max_rel, n_diff)
+    pair.close()
+    return ok, desc

@@ -1,5 +1,5 @@
 """A seeded subset of the randomised GPU-vs-oracle frames (tests/fuzz_cases.py; tools/fuzz_parity.py runs thousands:
-round 1 ran seeds 0-3059 with no mismatch)."""
+round 1 ran mesh seeds 0-3059 and analytic seeds 0-6299 with no mismatch)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -10,6 +10,16 @@ def test_random_scenes_match_the_oracle(rt, orc):
     failures = []
     for seed in range(48):
         ok, desc = random_case(rt, seed)
+        if not ok:
+            failures.append(desc)
+    assert not failures, "\n".join(failures)
+
+
+def test_random_analytic_scenes_match_the_oracle(rt, orc):
+    from fuzz_cases import random_analytic_case
+    failures = []
+    for seed in range(64):
+        ok, desc = random_analytic_case(rt, seed)
         if not ok:
             failures.append(desc)
     assert not failures, "\n".join(failures)
