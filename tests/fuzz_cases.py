@@ -24,6 +24,20 @@ def random_case(rt, seed):
         color = tuple(rs.uniform(0.2, 1.0, 3))
         mat = rt.ReflectionMaterial(color) if m < 0.25 else rt.BRDFMaterial(int(rs.randint(0, 8)), color) if m < 0.45 else rt.ColorInformation(color)
         objs.append((v, i, None, mat))
+    # ties: equal distances between faces of one object and between objects are decided by the reference's fold order
+    twist = rs.rand()
+    if twist < 0.15:     # every face of object 0 twice (the second copy in shuffled order)
+        v, i, n, mat = objs[0]
+        objs[0] = (v, np.ascontiguousarray(np.concatenate([i, i[rs.permutation(i.shape[0])]]), dtype=np.int32), n, mat)
+    elif twist < 0.3:    # object 0 again as another object, with its own material
+        v, i, n, mat = objs[0]
+        objs.append((v.copy(), i.copy(), None, rt.ColorInformation(tuple(rs.uniform(0.2, 1.0, 3)))))
+    elif twist < 0.4:    # some degenerate faces (two equal corners) and given, non-unit normals
+        v, i, n, mat = objs[0]
+        i = i.copy()
+        sel = rs.choice(i.shape[0], size=max(1, i.shape[0] // 50), replace=False)
+        i[sel, 2] = i[sel, 1]
+        objs[0] = (v, i, (rs.standard_normal(v.shape) * rs.uniform(0.5, 3.0)).astype(np.float32), mat)
     kind = int(rs.randint(0, 3))   # the reference's far light / a light inside the scene / one around it
     lo = (0.0, 100.0, 100.0) if kind == 0 else tuple(rs.uniform(-0.5, 0.5, 3) * scale) if kind == 1 else tuple(rs.uniform(-1.5, 1.5, 3) * scale)
     light = dict(origin=lo, emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
