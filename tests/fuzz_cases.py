@@ -120,3 +120,43 @@ def random_analytic_case(rt, seed):
         seed, len(objs), W, H, ms, float((o["hit_w"] > 0).mean()), "ok" if ok else "MISMATCH", ids_equal, w_equal, max_rel, n_diff)
     pair.close()
     return ok, desc
+
+
+def random_rays_case(rt, seed):
+    """mi355rt_trace_rays against the oracle on arbitrary rays: origins inside and outside the mesh, zero direction
+    components (1/d infinite), rays aimed exactly at vertices and edge midpoints (hits in several faces at one distance:
+    the tie rule), origins on the surface."""
+    rs = np.random.RandomState(7000 + seed)
+    scale = float(rs.choice([0.2, 3.0, 400.0]))
+    objs = []
+    for k in range(int(rs.randint(1, 3))):
+        v, i = rt.meshgen.blob(int(rs.randint(100, 4000)), span=scale * rs.uniform(0.4, 1.0), seed=int(rs.randint(1 << 20)))
+        v = (v + (rs.uniform(-0.3, 0.3, 3) * scale).astype(np.float32)).astype(np.float32)
+        objs.append((v, i, None, rt.ColorInformation((1, 1, 1))))
+    pair = Pair(objs, use_kdtree=bool(rs.rand() < 0.9))
+    cam, ocam, ost = pair.cameras(8, 8)
+    n = 3000
+    o = (rs.uniform(-0.8, 0.8, size=(n, 3)) * scale).astype(np.float32)
+    d = rs.standard_normal((n, 3)).astype(np.float32)
+    v0, i0 = objs[0][0], objs[0][1]
+    vt = v0[rs.randint(0, v0.shape[0], 600)]                    # aimed at vertices
+    d[:600] = vt - o[:600]
+    f = i0[rs.randint(0, i0.shape[0], 600)]
+    mid = ((v0[f[:, 0]].astype(np.float64) + v0[f[:, 1]]) / 2).astype(np.float32)   # aimed at edge midpoints
+    d[600:1200] = mid - o[600:1200]
+    o[1200:1400] = v0[rs.randint(0, v0.shape[0], 200)]         # origins on vertices
+    for c in range(3):                                          # zero components, of both signs
+        d[1400 + 100 * c:1500 + 100 * c, c] = 0.0 if c != 1 else -0.0
+    d[1700:1750, 0] = 0.0
+    d[1700:1750, 2] = 0.0
+    g = cam.getClosestIntersection(o, d)
+    r = pair.oscene.trace(ost, o, d)
+    hit = r["face"] >= 0
+    ok = (np.array_equal(g["face"], r["face"]) and np.array_equal(g["object"], r["object"])
+          and np.array_equal(g["w"].view(np.uint32), r["w"].view(np.uint32))
+          and np.array_equal(g["point"][hit].view(np.uint32), r["point"][hit].view(np.uint32))
+          and np.array_equal(g["normal"][hit].view(np.uint32), r["normal"][hit].view(np.uint32)))
+    desc = "rays seed %d scale %g objs %d hits %d of %d: %s (faces differing: %d)" % (
+        seed, scale, len(objs), int(hit.sum()), n, "ok" if ok else "MISMATCH", int((g["face"] != r["face"]).sum()))
+    pair.close()
+    return ok, desc

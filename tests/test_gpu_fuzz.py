@@ -1,5 +1,5 @@
 """A seeded subset of the randomised GPU-vs-oracle frames (tests/fuzz_cases.py; tools/fuzz_parity.py runs thousands:
-round 1 ran mesh seeds 0-3059 and analytic seeds 0-6299 with no mismatch)."""
+round 1 ran 4,560 mesh scenes, 6,300 analytic scenes and 1,000 ray batches with no mismatch)."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -20,6 +20,16 @@ def test_random_analytic_scenes_match_the_oracle(rt, orc):
     failures = []
     for seed in range(64):
         ok, desc = random_analytic_case(rt, seed)
+        if not ok:
+            failures.append(desc)
+    assert not failures, "\n".join(failures)
+
+
+def test_random_ray_batches_match_the_oracle(rt, orc):
+    from fuzz_cases import random_rays_case
+    failures = []
+    for seed in range(24):
+        ok, desc = random_rays_case(rt, seed)
         if not ok:
             failures.append(desc)
     assert not failures, "\n".join(failures)
