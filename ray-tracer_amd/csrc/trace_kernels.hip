@@ -454,7 +454,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       // fold does not depend on when it happens (see the tie rule), and slots of one leaf still arrive in slot order.
       if (CLOSEST) {
          const unsigned long long pm = __ballot(pend >= 0);
-         if (pm != 0ull && (resolve_req || exhausted || __popcll(pm) >= a.resolve_min || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
+         if (pm != 0ull && (resolve_req || exhausted || (int) __popcll(pm) >= a.resolve_min || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
             const float sd = st.k >= 0 ? a.sc.objs[st.k].shadow_distance : 0.0f;
             for (int pass = 0; pass < 2; pass++) {
                const bool doit = pend >= 0 && (pass == 0 || (pend & 1));
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
 
          // ---- (3) idle lanes take new rays from the queue
          const unsigned long long idle = __ballot(st.role == ROLE_IDLE);
-         if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
+         if (idle != 0ull && !exhausted && ((int) __popcll(idle) >= a.refill_min || idle == ~0ull)) {
             const unsigned want_n = (unsigned) __popcll(idle);
             if (STATS > 1 && lane == 0) d_refill++;
             // A band's queue of n rays is dealt out as a rows x spread matrix read down the columns: logical index L
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // Before the queue is dry a steal needs steal_min idle lanes (they would rather wait for a refill) -- except,
          // for shadow rays, from a ray that has been walked for age_min trips already: those few long rays are what
          // the launch ends up waiting for, so they get help as soon as a lane is free.
-         const bool steal_any = (exhausted && __popcll(thieves) >= a.tail_steal_min) || __popcll(thieves) >= a.steal_min;
+         const bool steal_any = (exhausted && (int) __popcll(thieves) >= a.tail_steal_min) || (int) __popcll(thieves) >= a.steal_min;
          const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || ((!FUSED || st.shadow) && age >= a.age_min)));
          if (thieves != 0ull && victims != 0ull) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
