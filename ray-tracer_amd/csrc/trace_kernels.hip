@@ -701,7 +701,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // for shadow rays, from a ray that has been walked for age_min trips already: those few long rays are what
          // the launch ends up waiting for, so they get help as soon as a lane is free.
          const bool steal_any = (exhausted && (int) __popcll(thieves) >= a.tail_steal_min) || (int) __popcll(thieves) >= a.steal_min;
-         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || ((!FUSED || st.shadow) && age >= a.age_min)));
+         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || (!CLOSEST && age >= a.age_min)));   // measured: no gain for queue rays, fused or not
          if (thieves != 0ull && victims != 0ull) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
             const int v_rank = rank_below(victims), t_rank = rank_below(thieves);
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             const float ox = __shfl(r.o.x, v, 64), oy = __shfl(r.o.y, v, 64), oz = __shfl(r.o.z, v, 64);
             const float dx = __shfl(r.d.x, v, 64), dy = __shfl(r.d.y, v, 64), dz = __shfl(r.d.z, v, 64);
             const float ix = __shfl(r.inv.x, v, 64), iy = __shfl(r.inv.y, v, 64), iz = __shfl(r.inv.z, v, 64);
-            const int v_age = __shfl(age, v, 64);
+            const int v_age = CLOSEST ? 0 : __shfl(age, v, 64);
             const int v_shadow = FUSED ? __shfl((int) st.shadow, v, 64) : 0;
             if (is_victim) ++bot;
             if (is_thief) {
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       // paths for a handful of lanes each would spend most of its issue slots on masked-off lanes, so
       // the minority state sits a trip out unless it is populous too (it becomes the majority soon).
       if (STATS > 1 && st.role == ROLE_OWNER) d_ray_trips++;
-      ++age;
+      if (!CLOSEST) ++age;
       const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
       const bool in_leaf = cur < 0;
       const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
@@ -1392,7 +1392,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
    a.both_min = tunable("MI355RT_BOTH_MIN", 12);
    a.resolve_min = tunable("MI355RT_RESOLVE_MIN", 12);
-   a.age_min = tunable(fuse_light ? "MI355RT_AGE_MIN_FUSED" : "MI355RT_AGE_MIN_CLOSEST", 1 << 30);
+   a.age_min = 1 << 30;   // shadow launches only
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, 6));
    if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
    return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
