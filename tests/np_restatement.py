@@ -278,3 +278,81 @@ def checker_color(mm, p, c1, c2, cell):   # CheckerboardMaterial.java:21-49
     one = (x % 2 == 0 and y % 2 == 0 and z % 2 == 0) or (x % 2 == 1 and y % 2 == 0 and z % 2 == 1) or \
         (x % 2 == 0 and y % 2 == 1 and z % 2 == 1)
     return [f32(v) for v in (c1 if one else c2)]
+
+
+# ---- the hierarchy itself, as the reference's recursion (small meshes only: pure Python) -------------------------
+def kd_build(vertices, faces, minmax, axis, depth, max_depth, max_children, use_kdtree):   # KDNode ctor, KDNode.java:29-90
+    """faces: list of (face id, (i0, i1, i2)); minmax: [lo3, hi3] as f32 lists.  Returns a dict node."""
+    node = {"minmax": [f32(x) for x in minmax[0]] + [f32(x) for x in minmax[1]], "faces": faces, "left": None, "right": None}
+    if not (use_kdtree and depth < max_depth and len(faces) > max_children):
+        return node
+    lo, hi = f32(minmax[0][axis]), f32(minmax[1][axis])
+    median = f32(f32(f32(hi - lo) / f32(2.0)) + lo)
+    left, right = [], []
+    for fid, tri in faces:
+        vals = [f32(vertices[i][axis]) for i in tri]
+        fmin, fmax = min(vals), max(vals)
+        if fmax <= median:
+            left.append((fid, tri))
+        elif fmin >= median:
+            right.append((fid, tri))
+        else:
+            left.append((fid, tri))
+            right.append((fid, tri))
+
+    def bounds(fs):   # RTStatics.getMinMax(vertices, faces, out), RTStatics.java:244-264
+        pts = [vertices[i] for _, tri in fs for i in tri]
+        return [[min(f32(p[c]) for p in pts) for c in range(3)], [max(f32(p[c]) for p in pts) for c in range(3)]]
+
+    nxt = (axis + 1) % 3
+    if left:
+        node["left"] = kd_build(vertices, left, bounds(left), nxt, depth + 1, max_depth, max_children, use_kdtree)
+    if right:
+        node["right"] = kd_build(vertices, right, bounds(right), nxt, depth + 1, max_depth, max_children, use_kdtree)
+    return node
+
+
+def kd_intersect(node, o, d, vertices, normals, eps, shadow_distance):   # KDNode.getChildIntersection, KDNode.java:93-123
+    """Returns (face id, [point3, normal3, w]) or None."""
+    if node["left"] is not None or node["right"] is not None:
+        tl = tr = None
+        if node["left"] is not None and aabb_intersection(o, d, node["left"]["minmax"]):
+            tl = kd_intersect(node["left"], o, d, vertices, normals, eps, shadow_distance)
+        if node["right"] is not None and aabb_intersection(o, d, node["right"]["minmax"]):
+            tr = kd_intersect(node["right"], o, d, vertices, normals, eps, shadow_distance)
+        if tl is None and tr is None:
+            return None
+        if tl is None:
+            return tr
+        if tr is None:
+            return tl
+        return tl if tl[1][6] < tr[1][6] else tr
+    closest = None
+    for fid, tri in node["faces"]:
+        if aabb_intersection(o, d, node["minmax"]):
+            t = intersects_triangle(o, d, [vertices[i] for i in tri], [normals[i] for i in tri], eps)
+            if t is not None and t[6] > shadow_distance and (closest is None or t[6] < closest[1][6]):
+                closest = (fid, t)
+    return closest
+
+
+def mesh_closest(vertices, normals, indices, o, d, eps, max_depth=20, max_children=5, use_kdtree=True, tree=None):
+    """KDTree ctor + KDTree.getChildIntersection + Camera.getClosestIntersection's acceptance for ONE mesh
+    (KDTree.java:24-65, Camera.java:203-211, Ray.java:9-13).  Returns (tree, hit or None)."""
+    if tree is None:
+        lo = [min(f32(v[c]) for v in vertices) for c in range(3)]     # over ALL vertices (KDTree.java:35-44)
+        hi = [max(f32(v[c]) for v in vertices) for c in range(3)]
+        span = max(f32(hi[0] - lo[0]), max(f32(hi[1] - lo[1]), f32(hi[2] - lo[2])))
+        tree = {"root": kd_build(vertices, [(k, tuple(int(x) for x in f)) for k, f in enumerate(indices)], [lo, hi], 0, 0,
+                                 max_depth, max_children, use_kdtree),
+                "shadow_distance": f32(span / f32(2000.0))}
+    o = [f32(x) for x in o]
+    d = vnormalize([f32(x) for x in d])
+    root = tree["root"]
+    hit = None
+    if aabb_intersection(o, d, root["minmax"]):          # Camera.java:205 object.intersects(ray)
+        if aabb_intersection(o, d, root["minmax"]):      # KDTree.getChildIntersection tests it again (KDTree.java:60)
+            hit = kd_intersect(root, o, d, vertices, normals, eps, tree["shadow_distance"])
+    if hit is not None and not (hit[1][6] > eps):         # Camera.java:208
+        hit = None
+    return tree, hit

@@ -2,6 +2,7 @@
 import ctypes as C
 
 import numpy as np
+import pytest
 
 import np_restatement as npr
 
@@ -168,3 +169,47 @@ def test_checkerboard_random(orc):
         assert out.tobytes() == np.array(ref, dtype=np.float32).tobytes()
         seen.add(tuple(out))
     assert seen == {(1.0, 1.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.0, 0.0)}
+
+
+@pytest.mark.parametrize("kind", ["blob", "soup", "doubled", "flat_no_tree"])
+def test_hierarchy_walk_against_the_recursive_restatement(orc, kind):
+    """The oracle's whole closest-hit query (hierarchy build with duplicated faces, both-children recursion, the fold's
+    tie rule, leaf loop, shadowDistance, Camera's acceptance) against a second, independent restatement written as the
+    reference's own recursion in Python (np_restatement.kd_build / kd_intersect): face, w, point and normal bit for bit."""
+    import ray_tracer_amd as rt
+    rs = np.random.RandomState({"blob": 1, "soup": 2, "doubled": 3, "flat_no_tree": 4}[kind])
+    if kind == "soup":
+        v, i = rt.meshgen.soup(160, span=0.3, tri_size=0.25, seed=5)       # big faces: heavy duplication over leaves
+    else:
+        v, i = rt.meshgen.blob(192 if kind == "blob" else 48, span=0.3, seed=7)   # doubled faces never separate: the depth limit ends it
+    if kind == "doubled":
+        i = np.ascontiguousarray(np.concatenate([i, i[rs.permutation(i.shape[0])]]), dtype=np.int32)   # equal w everywhere
+    n = rs.standard_normal(v.shape).astype(np.float32)
+    use_tree = kind != "flat_no_tree"
+    max_depth = 8 if kind == "doubled" else 20
+    osc = orc.OracleScene([(v, i, n, orc.material(diffuse=(1, 1, 1)))], max_depth=max_depth, max_children=5, use_kdtree=use_tree)
+    eps = osc.epsilon()
+    st = orc.settings(epsilon=eps)
+    m = 140
+    o = rs.uniform(-0.4, 0.4, size=(m, 3)).astype(np.float32)
+    d = rs.standard_normal((m, 3)).astype(np.float32)
+    d[:50] = v[rs.randint(0, v.shape[0], 50)] - o[:50]                      # aimed at vertices: several faces at one distance
+    f = i[rs.randint(0, i.shape[0], 30)]
+    d[50:80] = ((v[f[:, 0]].astype(np.float64) + v[f[:, 1]]) / 2).astype(np.float32) - o[50:80]   # at edge midpoints
+    d[80:90, 0] = 0.0
+    r = osc.trace(st, o, d)
+    tree = None
+    hits = 0
+    for k in range(m):
+        tree, hit = npr.mesh_closest(v, n, i, o[k], d[k], np.float32(eps), max_depth=max_depth, use_kdtree=use_tree, tree=tree)
+        if hit is None:
+            assert r["face"][k] == -1, k
+            continue
+        hits += 1
+        fid, t = hit
+        assert r["face"][k] == fid, (k, r["face"][k], fid)
+        assert np.float32(t[6]).view(np.uint32) == r["w"][k].view(np.uint32), k
+        assert np.array_equal(np.array(t[0:3], dtype=np.float32).view(np.uint32), r["point"][k].view(np.uint32)), k
+        assert np.array_equal(np.array(t[3:6], dtype=np.float32).view(np.uint32), r["normal"][k].view(np.uint32)), k
+    assert hits > 40
+    osc.close()
