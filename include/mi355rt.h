@@ -21,7 +21,8 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 3   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free */
+#define MI355RT_ABI_VERSION 4   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
+                                 * 4: mi355rt_render_device_noalloc */
 
 enum {
    MI355RT_OK = 0,
@@ -216,6 +217,22 @@ int mi355rt_host_free(void *ptr);
  * caller synchronises.  With tile_world > 1 only this rank's tiles are written. */
 int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings,
                           const mi355rt_frame *frame, void *hip_stream);
+
+/* The same frame as mi355rt_render_device for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (it has no device).  The call
+ * allocates, creates and frees nothing (no hipMalloc / hipFree / event creation): its frame scratch -- the queues and
+ * records mi355rt_render_device keeps in buffers it allocates on demand -- is a static device array of
+ * MI355RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.  The frame must fit
+ * it as ONE pass: ceil(8x8 pixel groups / 8) * 8 * 64 * multi_samples sample slots at 104 bytes each (204 with a
+ * ReflectionMaterial in the scene, 348 with a RefractionMaterial): 1,290,000 slots for a mesh-only scene, e.g.
+ * 1280x960 at 1 spp or 640x480 at 4 spp; anything larger fails with MI355RT_E_LIMIT and changes nothing.
+ * settings.collect_stats must be 0.  Inputs and outputs are as for mi355rt_render_device (device pointers in `frame`,
+ * asynchronous on hip_stream unless the scene has mirrors or refraction, whose bounce loop reads a queue size back).
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads, two
+ * scenes) race; calls in sequence on one stream are safe, whatever the previous call left behind. */
+#define MI355RT_NOALLOC_SCRATCH_BYTES (128u << 20)
+int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings,
+                                  const mi355rt_frame *frame, void *hip_stream);
 
 /* Counters of the most recent render on this scene that ran with settings.collect_stats != 0
  * (blocking: synchronises the scene's device). */

@@ -16,6 +16,7 @@ OBJ_MESH, OBJ_SPHERE, OBJ_PLANE = 0, 1, 2
 MAX_REFRACTION_TERMS = 8
 LIGHTING_PLAIN, LIGHTING_PHONG = 0, 1
 E_ARG, E_DEVICE, E_MEMORY, E_LIMIT, E_IO = -1, -2, -3, -4, -5
+NOALLOC_SCRATCH_BYTES = 128 << 20
 
 c_float_p = C.POINTER(C.c_float)
 c_int32_p = C.POINTER(C.c_int32)
@@ -100,6 +101,7 @@ PROTOTYPES = {
     "mi355rt_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "mi355rt_host_free": (C.c_int, [C.c_void_p]),
     "mi355rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
+    "mi355rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
     "mi355rt_frame_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mi355rt_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile), C.c_int]),
     "mi355rt_image_argb8": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int, c_uint32_p, C.c_int32]),

@@ -1,6 +1,6 @@
 // api.cpp -- the C ABI of libmi355rt.so (include/mi355rt.h): handles, error reporting, host-side
 // set-up (camera constants, BRDF table remap) and HIP memory / launch plumbing.
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cmath>
@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -22,6 +23,37 @@
 #include "scene_build.hpp"
 
 using namespace mi355rt;
+
+// The frame scratch of mi355rt_render_device_noalloc (include/mi355rt.h): a file-scope device array instead of
+// hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy at its own address until the process ends.
+// In host code the NAME is only a stand-in for the symbol, never a device address: noalloc_scratch_ptr() resolves it
+// once per device with hipGetSymbolAddress, and host code uses that pointer wherever it needs the memory.
+static __device__ __align__(256) unsigned char scratch[MI355RT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[MAX_DEVICES] = { nullptr };
+
+// the address of `scratch` on `device`, which must be the current device; resolved on first use per device
+hipError_t noalloc_scratch_ptr(int device, void **out)
+{
+   *out = nullptr;
+   if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+   std::lock_guard<std::mutex> lock(g_scratch_mutex);
+   if (!g_scratch_ptr[device]) {
+      void *ptr = nullptr;
+      const hipError_t e = hipGetSymbolAddress((void **) &ptr, HIP_SYMBOL(scratch));
+      if (e != hipSuccess) return e;
+      if (!ptr) return hipErrorInvalidSymbol;
+      g_scratch_ptr[device] = ptr;
+   }
+   *out = g_scratch_ptr[device];
+   return hipSuccess;
+}
+
+}   // namespace
 
 namespace {
 
@@ -110,6 +142,8 @@ struct mi355rt_scene {
    bool has_mirror = false;
    uint64_t device_bytes = 0;
    uint32_t *d_counters = nullptr;   // CNT_WORDS
+   unsigned long long *h_readback = nullptr;   // page-locked, N_STATS words: where run_frame reads queue sizes and counters back to
+   void *noalloc_scratch = nullptr;  // this device's copy of the static scratch array (mi355rt_render_device_noalloc)
    bool stats_valid = false;
    mi355rt_stats stats_accum {};
    unsigned long long diag[N_STATS] = { 0 };
@@ -152,6 +186,7 @@ void release_scene(mi355rt_scene *s)
    if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
    if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
    if (s->d_counters) (void) hipFree(s->d_counters);
+   if (s->h_readback) (void) hipHostFree(s->h_readback);
    if (s->d_rgb) (void) hipFree(s->d_rgb);
    if (s->d_hit_id) (void) hipFree(s->d_hit_id);
    if (s->d_hit_w) (void) hipFree(s->d_hit_w);
@@ -539,17 +574,25 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
 }
 
 // one frame = passes of at most PASS_SLOTS sample slots, each a run of the kernel pipeline
-int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_times, hipStream_t stream)
+// `fixed`: the frame runs as ONE pass in these buffers (with `fixed_counters` as its counter block) and nothing is
+// allocated, created or freed on the way -- mi355rt_render_device_noalloc; else the scene's own scratch, grown on demand.
+int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_times, hipStream_t stream, const FrameScratch *fixed = nullptr,
+              uint32_t *fixed_counters = nullptr)
 {
    if (n_micro == 0) return MI355RT_OK;
    if (s->pending_times.size() > 4096)
       if (int rc = resolve_times(s)) return rc;
    LaunchTimer timer(s, collect_times, stream);
    const size_t slots_per_micro = (size_t) 64 * (size_t) p.multi_samples;
-   const long long micro_per_pass = (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
+   const long long micro_per_pass = fixed ? n_micro : (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
    const long long first_pass = std::min(n_micro, micro_per_pass);
-   if (int rc = ensure_scratch(s, (size_t) ((first_pass + N_BANDS - 1) / N_BANDS) * N_BANDS * slots_per_micro, s->has_mirror || s->has_refraction, s->has_refraction)) return rc;
-   const FrameScratch &fs = s->scratch;
+   const size_t first_slots = (size_t) ((first_pass + N_BANDS - 1) / N_BANDS) * N_BANDS * slots_per_micro;
+   if (fixed) {
+      if (fixed->cap < first_slots) return fail(MI355RT_E_LIMIT, "frame does not fit the fixed scratch");
+   } else if (int rc = ensure_scratch(s, first_slots, s->has_mirror || s->has_refraction, s->has_refraction)) {
+      return rc;
+   }
+   const FrameScratch &fs = fixed ? *fixed : s->scratch;
    p.samples = fs.samples;
    p.rays0 = fs.rays0;
    p.hits0 = fs.hits0;
@@ -562,7 +605,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
    p.hit_obj1 = fs.hit_obj1;
    p.refr_parent = fs.refr_parent;
    p.refr_terms = fs.refr_terms;
-   p.counters = s->d_counters;
+   p.counters = fixed ? fixed_counters : s->d_counters;
    if (p.stats) {
       s->stats_accum = mi355rt_stats {};
       s->stats_valid = true;
@@ -580,7 +623,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       // afresh over all waves end sooner than each wave's own).
       p.fused_shadow = fuse_policy == 2 || (fuse_policy == 1 && slots >= FUSE_MIN_SLOTS) ? 1 : 0;
       p.phong_in_shade = p.fused_shadow && !s->has_mirror && !s->has_refraction ? 1 : 0;
-      HIP_TRY(hipMemsetAsync(s->d_counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
+      HIP_TRY(hipMemsetAsync(p.counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
       HIP_TRY(timer.run(MI355RT_K_GENERATE, [&] { return launch_generate(p, stream); }));
       int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
       auto next_cursor = [&]() -> int { return CNT_CURSOR0 + 8 * (cursor_set++); };
@@ -597,11 +640,11 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
          // mirror / refraction bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
          int cur = 0;
          for (int bounce = 0; bounce <= p.max_mirror_bounces; bounce++) {
-            uint32_t n_band[N_BANDS];
-            HIP_TRY(hipMemcpyAsync(n_band, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), sizeof(n_band), hipMemcpyDeviceToHost, stream));
+            uint32_t *n_band = (uint32_t *) s->h_readback;   // page-locked: a plain DMA, no staging buffer
+            HIP_TRY(hipMemcpyAsync(n_band, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), N_BANDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             unsigned long long n_sec = 0;
-            for (uint32_t nb : n_band) n_sec += nb;
+            for (int b = 0; b < N_BANDS; b++) n_sec += n_band[b];
             if (n_sec == 0) break;
             const int cur_cnt = cur == 0 ? CNT_SEC_A : CNT_SEC_B, nxt_cnt = cur == 0 ? CNT_SEC_B : CNT_SEC_A;
             if (cursor_set >= CNT_CURSOR_SETS - 1) cursor_set = 1;   // keep the last set for the shadow launch
@@ -626,8 +669,8 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       }
       HIP_TRY(timer.run(MI355RT_K_RESOLVE, [&] { return launch_resolve(p, stream); }));
       if (p.stats) {
-         unsigned long long h[N_STATS];
-         HIP_TRY(hipMemcpyAsync(h, p.counters + CNT_STATS, sizeof(h), hipMemcpyDeviceToHost, stream));
+         unsigned long long *h = s->h_readback;
+         HIP_TRY(hipMemcpyAsync(h, p.counters + CNT_STATS, N_STATS * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
          HIP_TRY(hipStreamSynchronize(stream));
          for (int q = 0; q < N_STATS; q++) s->diag[q] = (m0 == 0 ? 0ull : s->diag[q]) + h[q];
          s->stats_accum.primary_rays += h[0];
@@ -851,9 +894,16 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       return rc;
    }
    hipError_t e = hipMalloc((void **) &s->d_counters, CNT_WORDS * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipHostMalloc((void **) &s->h_readback, N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
    if (e != hipSuccess) {
       release_scene(s);
       return hip_fail(e, "hipMalloc(counters)");
+   }
+   // set-up for mi355rt_render_device_noalloc: this device's address of the static scratch array, while the device is current
+   e = noalloc_scratch_ptr(device, &s->noalloc_scratch);
+   if (e != hipSuccess) {
+      release_scene(s);
+      return hip_fail(e, "hipGetSymbolAddress(scratch)");
    }
    int cus = 0;
    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
@@ -1000,6 +1050,64 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
    p.hit_obj = frame->hit_obj;
    p.hit_w = frame->hit_w;
    return run_frame(scene, p, n_micro, (settings->collect_stats & MI355RT_COLLECT_TIMES) != 0, (hipStream_t) hip_stream);
+}
+
+int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_frame *frame,
+                                  void *hip_stream)
+{
+   if (!scene || !frame || !settings) return fail(MI355RT_E_ARG, "null argument");
+   if (settings->collect_stats != 0) return fail(MI355RT_E_ARG, "mi355rt_render_device_noalloc takes collect_stats == 0 (counting and timing create events and read back)");
+   FrameArgs p;
+   long long n_micro = 0;
+   if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
+   DeviceScope scope(scene->device);
+   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   unsigned char *base = (unsigned char *) scene->noalloc_scratch;   // resolved at scene creation (hipGetSymbolAddress), per device
+   if (!base) return fail(MI355RT_E_DEVICE, "the static scratch array was not resolved on this device");
+   // the whole frame is one pass: every band's sub-queue of every record array must fit the array
+   const bool with_mirror = scene->has_mirror || scene->has_refraction, with_refraction = scene->has_refraction;
+   const unsigned long long slots = (unsigned long long) ((n_micro + N_BANDS - 1) / N_BANDS) * N_BANDS * 64ull * (unsigned long long) settings->multi_samples;
+   const unsigned long long per_slot = 104ull + (with_mirror ? 100ull : 0ull) + (with_refraction ? 16ull * (1 + MAX_REFRACTION_TERMS) : 0ull);
+   constexpr unsigned long long HEAD = 4096, ALIGN_SLACK = 12 * 256;   // counters; each of up to 12 arrays starts on a 256-byte boundary
+   if (slots * per_slot + HEAD + ALIGN_SLACK > (unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES)
+      return fail(MI355RT_E_LIMIT, "mi355rt_render_device_noalloc: " + std::to_string(slots) + " sample slots x " + std::to_string(per_slot) +
+                                       " bytes exceed the static scratch of " + std::to_string((unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES) +
+                                       " bytes; use mi355rt_render_device for this frame");
+   static_assert(CNT_WORDS * sizeof(uint32_t) <= 4096, "the counter block sits in the first 4 KiB of the scratch");
+   FrameScratch fs;
+   size_t off = HEAD;
+   auto carve = [&](size_t bytes) -> void * {
+      void *q = base + off;
+      off = (off + bytes + 255) & ~(size_t) 255;
+      return q;
+   };
+   fs.cap = (size_t) slots;
+   fs.with_mirror = with_mirror;
+   fs.with_refraction = with_refraction;
+   fs.samples = (float *) carve(slots * 16);
+   fs.rays0 = (float *) carve(slots * 32);
+   fs.hits0 = (float *) carve(slots * 32);
+   fs.mat0 = (float *) carve(slots * 16);
+   fs.hit_obj0 = (int32_t *) carve(slots * 4);
+   fs.shadow = (uint32_t *) carve(slots * 4);
+   if (with_mirror) {
+      fs.rays1[0] = (float *) carve(slots * 32);
+      fs.rays1[1] = (float *) carve(slots * 32);
+      fs.hits1 = (float *) carve(slots * 32);
+      fs.hit_obj1 = (int32_t *) carve(slots * 4);
+   }
+   if (with_refraction) {
+      fs.refr_parent = (float *) carve(slots * 16);
+      fs.refr_terms = (float *) carve(slots * 16 * MAX_REFRACTION_TERMS);
+   }
+   p.rgb = frame->rgb;
+   p.argb8 = frame->argb8;
+   p.hit_id = frame->hit_id;
+   p.hit_obj = frame->hit_obj;
+   p.hit_w = frame->hit_w;
+   // the array keeps the previous call's contents: run_frame clears the counter block at the start of the pass (the
+   // only part that must start at zero); every queue record is written before it is read
+   return run_frame(scene, p, n_micro, false, (hipStream_t) hip_stream, &fs, (uint32_t *) base);
 }
 
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,

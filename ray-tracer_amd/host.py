@@ -492,6 +492,12 @@ class Camera:
         _abi.check(self._lib.mi355rt_render_device(self.scene._handle, C.byref(self._cam), C.byref(st), C.byref(frame),
                                                    C.c_void_p(stream) if stream else None))
 
+    def render_device_noalloc(self, frame, stream=None, **kw):
+        """mi355rt_render_device_noalloc: the same frame out of the library's static device scratch (no allocation)."""
+        st = self.settings(**kw)
+        _abi.check(self._lib.mi355rt_render_device_noalloc(self.scene._handle, C.byref(self._cam), C.byref(st), C.byref(frame),
+                                                           C.c_void_p(stream) if stream else None))
+
     def frame_stats(self):
         s = _abi.Stats()
         _abi.check(self._lib.mi355rt_frame_stats(self.scene._handle, C.byref(s)))
