@@ -21,8 +21,8 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 4   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
-                                 * 4: mi355rt_render_device_noalloc */
+#define MI355RT_ABI_VERSION 5   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
+                                 * 4: mi355rt_render_device_noalloc; 5: mi355rt_render returns hit_obj, mi355rt_mesh_desc.compute_kdtree */
 
 enum {
    MI355RT_OK = 0,
@@ -63,6 +63,8 @@ typedef struct {
    const int32_t *indices; /* n_faces * 3 */
    uint32_t n_vertices, n_faces;
    mi355rt_material material;
+   int32_t compute_kdtree; /* this TriangleMesh's own computeKDTree argument (TriangleMesh.java:23,89): 0 = build_opts.use_kdtree
+                            * decides, > 0 build the hierarchy, < 0 keep every face in one leaf */
 } mi355rt_mesh_desc;
 
 typedef struct {
@@ -200,9 +202,10 @@ int mi355rt_camera_setup(const mi355rt_scene *scene, const float orientation_deg
 
 /* Replaces Camera.createImage() + RenderThread.run() + Camera.setPixel() (Camera.java:119-185,
  * RenderThread.java:30-69, Camera.java:96-108): blocking; host output buffers (any may be NULL):
- * rgb W*H*3 f32 row-major, hit_id / hit_w W*H for sample 0. */
+ * rgb W*H*3 f32 row-major; hit_id / hit_obj / hit_w W*H for sample 0 (face index within its mesh, index of the
+ * object in Scene.objects -- IntersectionInformation.intersectionObject --, IntersectionInformation.w; -1, -1, 0 = miss). */
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
-                   int32_t *hit_id_out, float *hit_w_out);
+                   int32_t *hit_id_out, int32_t *hit_obj_out, float *hit_w_out);
 
 /* Page-locked host memory for the buffers mi355rt_render writes to: its device-to-host copies then run at PCIe
  * speed instead of through the runtime's staging buffers (figures in DESIGN.md section 5).  No counterpart in the
@@ -214,7 +217,13 @@ int mi355rt_host_free(void *ptr);
 
 /* Same frame, outputs left in device memory (pointers in `frame` are device pointers on the
  * scene's device).  Asynchronous on `hip_stream` (a hipStream_t, NULL = the null stream); the
- * caller synchronises.  With tile_world > 1 only this rank's tiles are written. */
+ * caller synchronises.  With tile_world > 1 only this rank's tiles are written.
+ * The call BLOCKS the host (it is still ordered on hip_stream) in three cases: the scene holds a ReflectionMaterial
+ * or RefractionMaterial (one 32-byte read-back of the bounce queue's size per bounce decides whether another bounce
+ * launch follows); settings.collect_stats has MI355RT_COLLECT_COUNTS / _DIAG (one read-back of the counters per
+ * pass); and a call that needs more frame scratch than the scene holds so far (the first one, or a larger frame)
+ * frees and allocates device memory, which synchronises the device.  Mesh-only Phong / plain frames of a size the
+ * scene has rendered before return at once: that is what frames in flight on several streams rely on. */
 int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings,
                           const mi355rt_frame *frame, void *hip_stream);
 

@@ -272,16 +272,16 @@ class Scene {
       : objects(std::move(objs)), light(l), cameraOrientation(orientation), lightingModel(model.kind()), fov(fieldOfView)
    {
       std::vector<mi355rt_object_desc> descs(objects.size(), mi355rt_object_desc {});
-      bool kd = true, brdf = false;
+      bool brdf = false;
       for (size_t k = 0; k < objects.size(); k++) {   // TriangleMesh, Sphere or Plane, in Scene.objects order
          const BoundingVolume &m = *objects[k];
          m.fill(descs[k]);
          descs[k].mesh.material = m.material;
          descs[k].ext = m.materialExt;
-         kd = kd && m.computeKDTree;
+         descs[k].mesh.compute_kdtree = m.computeKDTree ? 1 : -1;   // per mesh, as TriangleMesh.java:89 passes it on
          brdf = brdf || m.material.kind == MI355RT_MAT_BRDF;
       }
-      mi355rt_build_opts opts { RTStatics::MAX_DEPTH, RTStatics::MAX_CHILDREN, kd ? 1 : 0, device };
+      mi355rt_build_opts opts { RTStatics::MAX_DEPTH, RTStatics::MAX_CHILDREN, 1, device };
       check(mi355rt_scene_create_objects(descs.data(), (uint32_t) descs.size(), &opts, &handle_));
       if (brdf) {
          const BRDFMaterial::Tables &t = BRDFMaterial::tables();
@@ -309,6 +309,7 @@ class Camera {
    uint64_t rngSeed = 0;   // the reference's jitter RNG is unseeded (RenderThread.java:32)
    mi355rt_camera cam {};  // origin, rotation, viewportWidth / viewportHeight as the reference's constructor derives them
    std::vector<int32_t> hitId;
+   std::vector<int32_t> hitObj;   // index into Scene.objects, -1 = miss
    std::vector<float> hitW;
 
    Camera(const Scene &s, int ms, int brdf, float nearPlane, int width, int height)
@@ -345,9 +346,10 @@ class Camera {
       const size_t n = (size_t) screenWidth * (size_t) screenHeight;
       rows_.assign(3 * n, 0.0f);
       hitId.assign(n, -1);
+      hitObj.assign(n, -1);
       hitW.assign(n, 0.0f);
       const mi355rt_settings st = settings();
-      check(mi355rt_render(scene.handle(), &cam, &st, rows_.data(), hitId.data(), hitW.data()));
+      check(mi355rt_render(scene.handle(), &cam, &st, rows_.data(), hitId.data(), hitObj.data(), hitW.data()));
       std::vector<ActionListener> fire;
       fire.swap(listeners_);
       for (ActionListener &l : fire) l(1, "finished");

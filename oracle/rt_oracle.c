@@ -1139,6 +1139,7 @@ int orc_scene_create_objects(const orc_object_desc *objects, uint32_t n_objects,
       int c;
       int32_t *faces;
       buildctx b;
+      orc_build_opts obj_opts;
       o->kind = od->kind;
       o->mat = md->material;
       o->ext = od->ext;
@@ -1181,7 +1182,9 @@ int orc_scene_create_objects(const orc_object_desc *objects, uint32_t n_objects,
       faces = (int32_t *) malloc(sizeof(int32_t) * (size_t) (md->n_faces ? md->n_faces : 1));
       for (f = 0; f < md->n_faces; f++) faces[f] = (int32_t) f;
       b.o = o;
-      b.opts = opts;
+      obj_opts = *opts;   /* computeKDTree is per TriangleMesh in the reference (TriangleMesh.java:89) */
+      if (md->compute_kdtree != 0) obj_opts.use_kdtree = md->compute_kdtree > 0;
+      b.opts = &obj_opts;
       b.stats_o = o;
       o->root = kdnode_new(&b, faces, md->n_faces, (const float(*)[3]) o->mm, 0, 0);
    }

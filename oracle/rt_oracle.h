@@ -48,6 +48,7 @@ typedef struct {
    const int32_t *indices;  /* n_faces * 3 */
    uint32_t n_vertices, n_faces;
    orc_material material;
+   int32_t compute_kdtree;  /* TriangleMesh's own computeKDTree (TriangleMesh.java:89): 0 = opts->use_kdtree decides, > 0 yes, < 0 no */
 } orc_mesh_desc;
 
 typedef struct {

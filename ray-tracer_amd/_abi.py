@@ -31,7 +31,7 @@ class Material(C.Structure):
 
 class MeshDesc(C.Structure):
     _fields_ = [("vertices", c_float_p), ("normals", c_float_p), ("indices", c_int32_p),
-                ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32), ("material", Material)]
+                ("n_vertices", C.c_uint32), ("n_faces", C.c_uint32), ("material", Material), ("compute_kdtree", C.c_int32)]
 
 
 class MaterialExt(C.Structure):
@@ -97,7 +97,7 @@ PROTOTYPES = {
     "mi355rt_scene_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mi355rt_camera_setup": (C.c_int, [C.c_void_p, c_float_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                        C.POINTER(CameraDesc)]),
-    "mi355rt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), c_float_p, c_int32_p, c_float_p]),
+    "mi355rt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), c_float_p, c_int32_p, c_int32_p, c_float_p]),
     "mi355rt_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
     "mi355rt_host_free": (C.c_int, [C.c_void_p]),
     "mi355rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),

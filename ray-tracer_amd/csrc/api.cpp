@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -68,6 +69,32 @@ int fail(int code, const std::string &msg)
 int hip_fail(hipError_t e, const char *what)
 {
    return fail(e == hipErrorOutOfMemory ? MI355RT_E_MEMORY : MI355RT_E_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// No exception may leave an extern "C" function (it would terminate the host process -- a JVM behind the JNI shim):
+// every entry point's body runs inside guarded().
+template <typename F> int guarded(F &&body) noexcept
+{
+   int code = MI355RT_E_ARG;
+   const char *what = "unexpected C++ exception";
+   try {
+      return body();
+   } catch (const std::bad_alloc &) {
+      code = MI355RT_E_MEMORY;
+      what = "out of host memory";
+   } catch (const std::length_error &) {
+      code = MI355RT_E_MEMORY;
+      what = "out of host memory (size beyond what a container holds)";
+   } catch (const std::exception &) {
+      what = "unexpected C++ exception (std::exception)";
+   } catch (...) {
+   }
+   try {
+      g_error = what;
+   } catch (...) {
+      g_error.clear();
+   }
+   return code;
 }
 
 #define HIP_TRY(expr)                                  \
@@ -160,6 +187,7 @@ struct mi355rt_scene {
    // frame buffers of the host-buffer render entry point
    float *d_rgb = nullptr;
    int32_t *d_hit_id = nullptr;
+   int32_t *d_hit_obj = nullptr;
    float *d_hit_w = nullptr;
    size_t frame_pixels = 0;
 };
@@ -175,7 +203,7 @@ void free_scratch(FrameScratch &fs)
    fs = FrameScratch();
 }
 
-void release_scene(mi355rt_scene *s)
+void release_scene_impl(mi355rt_scene *s)
 {
    if (!s) return;
    if (s->d_nodes) (void) hipFree(s->d_nodes);
@@ -189,6 +217,7 @@ void release_scene(mi355rt_scene *s)
    if (s->h_readback) (void) hipHostFree(s->h_readback);
    if (s->d_rgb) (void) hipFree(s->d_rgb);
    if (s->d_hit_id) (void) hipFree(s->d_hit_id);
+   if (s->d_hit_obj) (void) hipFree(s->d_hit_obj);
    if (s->d_hit_w) (void) hipFree(s->d_hit_w);
    free_scratch(s->scratch);
    for (const mi355rt_scene::TimedLaunch &t : s->pending_times) {
@@ -693,706 +722,773 @@ int mi355rt_abi_version(void) { return MI355RT_ABI_VERSION; }
 
 int mi355rt_device_count(void)
 {
-   int n = 0;
-   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-   return n;
+   return guarded([&]() -> int {
+      int n = 0;
+      if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+      return n;
+   });
 }
 
 int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_meshes, const mi355rt_build_opts *opts, mi355rt_scene **out)
 {
-   if (!out) return fail(MI355RT_E_ARG, "out is null");
-   *out = nullptr;
-   if (!opts) return fail(MI355RT_E_ARG, "build options are null");
-   if (n_meshes && !objects) return fail(MI355RT_E_ARG, "objects is null");
-   if (n_meshes > (uint32_t) MAX_OBJECTS) return fail(MI355RT_E_LIMIT, "more than " + std::to_string(MAX_OBJECTS) + " objects");
-   for (uint32_t i = 0; i < n_meshes; i++) {
-      const mi355rt_object_desc &od = objects[i];
-      if (od.kind > MI355RT_OBJ_PLANE) return fail(MI355RT_E_ARG, "unknown kind of object " + std::to_string(i));
-      if (od.mesh.material.kind > MI355RT_MAT_CHECKERBOARD) return fail(MI355RT_E_ARG, "unknown material kind on object " + std::to_string(i));
-      if (od.kind == MI355RT_OBJ_PLANE && (od.n_corners < 3 || od.n_corners > 4))
-         return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": a plane takes 3 or 4 corners");
-   }
-   int n_dev = 0;
-   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
-   int device = opts->device;
-   if (device < 0) {
-      if (hipGetDevice(&device) != hipSuccess) return fail(MI355RT_E_DEVICE, "hipGetDevice failed");
-   }
-   if (device >= n_dev) return fail(MI355RT_E_ARG, "device ordinal out of range");
-   DeviceScope scope(device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-
-   BuildOptions bo;
-   bo.max_depth = opts->max_depth;
-   bo.max_children = opts->max_children;
-   bo.use_kdtree = opts->use_kdtree != 0;
-
-   mi355rt_scene *s = new (std::nothrow) mi355rt_scene();
-   if (!s) return fail(MI355RT_E_MEMORY, "out of host memory");
-   s->device = device;
-   for (int c = 0; c < 3; c++) {
-      s->smin[c] = jm::kFloatMax;
-      s->smax[c] = -jm::kFloatMax;
-   }
-   std::vector<DevObject> dev_objs(n_meshes ? n_meshes : 1);
-   std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
-   std::vector<DevObjectExt> dev_ext(dev_objs.size());
-   std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
-   // all objects share one node array, one slot array and one normal array (links absolute); each object's part is
-   // built on the host (scene_build.cpp) or on the GPU (gpu_build.hip) and copied to its place at the end
-   std::vector<ScenePart> parts(n_meshes ? n_meshes : 1);
-   auto free_parts = [&parts]() {
-      for (ScenePart &p : parts) gpu_build_free(p.gpu);
-   };
-   bool boxes_finite = true;
-   std::vector<float> all_fnrm;
-   size_t slot_total = 0, face_total = 0, node_total = 0;
-   const char *builder_env = getenv("MI355RT_BUILDER");   // "host": never build on the GPU (tuning / tests); default: GPU where it applies
-   const bool allow_gpu_build = !(builder_env && std::string(builder_env) == "host");
-
-   try {
+   return guarded([&]() -> int {
+      if (!out) return fail(MI355RT_E_ARG, "out is null");
+      *out = nullptr;
+      if (!opts) return fail(MI355RT_E_ARG, "build options are null");
+      if (n_meshes && !objects) return fail(MI355RT_E_ARG, "objects is null");
+      if (n_meshes > (uint32_t) MAX_OBJECTS) return fail(MI355RT_E_LIMIT, "more than " + std::to_string(MAX_OBJECTS) + " objects");
       for (uint32_t i = 0; i < n_meshes; i++) {
          const mi355rt_object_desc &od = objects[i];
-         const mi355rt_mesh_desc &md = od.mesh;
-         DevObjectExt &ext = dev_ext[i];
-         ext.refraction_index = od.ext.refraction_index;
-         std::memcpy(ext.color1, od.ext.checker_color1, sizeof(ext.color1));
-         std::memcpy(ext.color2, od.ext.checker_color2, sizeof(ext.color2));
-         std::memcpy(ext.cell, od.ext.checker_cell, sizeof(ext.cell));
-         if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
-         if (md.material.kind == MI355RT_MAT_REFRACTION) s->has_refraction = true;
-         if (od.kind != MI355RT_OBJ_MESH) {
-            const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
+         if (od.kind > MI355RT_OBJ_PLANE) return fail(MI355RT_E_ARG, "unknown kind of object " + std::to_string(i));
+         if (od.mesh.material.kind > MI355RT_MAT_CHECKERBOARD) return fail(MI355RT_E_ARG, "unknown material kind on object " + std::to_string(i));
+         if (od.kind == MI355RT_OBJ_PLANE && (od.n_corners < 3 || od.n_corners > 4))
+            return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": a plane takes 3 or 4 corners");
+      }
+      int n_dev = 0;
+      if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
+      int device = opts->device;
+      if (device < 0) {
+         if (hipGetDevice(&device) != hipSuccess) return fail(MI355RT_E_DEVICE, "hipGetDevice failed");
+      }
+      if (device >= n_dev) return fail(MI355RT_E_ARG, "device ordinal out of range");
+      DeviceScope scope(device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+
+      BuildOptions bo;
+      bo.max_depth = opts->max_depth;
+      bo.max_children = opts->max_children;
+      bo.use_kdtree = opts->use_kdtree != 0;
+
+      mi355rt_scene *s = new (std::nothrow) mi355rt_scene();
+      if (!s) return fail(MI355RT_E_MEMORY, "out of host memory");
+      struct SceneGuard {   // an exception on the way (std::bad_alloc from a vector) must not leak the scene or its device memory
+         mi355rt_scene *s;
+         ~SceneGuard() { release_scene_impl(s); }
+      } guard { s };
+      auto release_scene = [&guard](mi355rt_scene *) {   // the early returns below
+         release_scene_impl(guard.s);
+         guard.s = nullptr;
+      };
+      s->device = device;
+      for (int c = 0; c < 3; c++) {
+         s->smin[c] = jm::kFloatMax;
+         s->smax[c] = -jm::kFloatMax;
+      }
+      std::vector<DevObject> dev_objs(n_meshes ? n_meshes : 1);
+      std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
+      std::vector<DevObjectExt> dev_ext(dev_objs.size());
+      std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
+      // all objects share one node array, one slot array and one normal array (links absolute); each object's part is
+      // built on the host (scene_build.cpp) or on the GPU (gpu_build.hip) and copied to its place at the end
+      std::vector<ScenePart> parts(n_meshes ? n_meshes : 1);
+      struct PartsGuard {
+         std::vector<ScenePart> &parts;
+         ~PartsGuard()
+         {
+            for (ScenePart &p : parts) gpu_build_free(p.gpu);   // idempotent
+         }
+      } parts_guard { parts };
+      auto free_parts = [&parts]() {
+         for (ScenePart &p : parts) gpu_build_free(p.gpu);
+      };
+      bool boxes_finite = true;
+      std::vector<float> all_fnrm;
+      size_t slot_total = 0, face_total = 0, node_total = 0;
+      const char *builder_env = getenv("MI355RT_BUILDER");   // "host": never build on the GPU (tuning / tests); default: GPU where it applies
+      const bool allow_gpu_build = !(builder_env && std::string(builder_env) == "host");
+
+      try {
+         for (uint32_t i = 0; i < n_meshes; i++) {
+            const mi355rt_object_desc &od = objects[i];
+            const mi355rt_mesh_desc &md = od.mesh;
+            DevObjectExt &ext = dev_ext[i];
+            ext.refraction_index = od.ext.refraction_index;
+            std::memcpy(ext.color1, od.ext.checker_color1, sizeof(ext.color1));
+            std::memcpy(ext.color2, od.ext.checker_color2, sizeof(ext.color2));
+            std::memcpy(ext.cell, od.ext.checker_cell, sizeof(ext.cell));
+            if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
+            if (md.material.kind == MI355RT_MAT_REFRACTION) s->has_refraction = true;
+            if (od.kind != MI355RT_OBJ_MESH) {
+               const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
+               if (!err.empty()) {
+                  free_parts();
+                  release_scene(s);
+                  return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": " + err);
+               }
+               continue;
+            }
+            ScenePart &part = parts[i];
+            // The GPU builder takes every mesh whose root splits and whose vertices are all finite (Java's Math.min / max
+            // treat NaN specially; the host builder restates that, the GPU's integer-key min / max do not).
+            BuildOptions bo_obj = bo;   // computeKDTree is per TriangleMesh in the reference (TriangleMesh.java:23,89)
+            if (md.compute_kdtree != 0) bo_obj.use_kdtree = md.compute_kdtree > 0;
+            bool gpu_build = allow_gpu_build && bo_obj.use_kdtree && bo.max_depth >= 1 && md.n_faces > (uint32_t) std::max(bo.max_children, 0) &&
+                             md.vertices && md.indices;
+            for (size_t v = 0; gpu_build && v < 3 * (size_t) md.n_vertices; v++) gpu_build = std::isfinite(md.vertices[v]);
+            bo_obj.build_tree = !gpu_build;
+            BuiltObject bo_out;
+            const auto t_prep = std::chrono::steady_clock::now();
+            const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo_obj, bo_out);
             if (!err.empty()) {
                free_parts();
                release_scene(s);
-               return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": " + err);
+               return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
             }
-            continue;
-         }
-         ScenePart &part = parts[i];
-         // The GPU builder takes every mesh whose root splits and whose vertices are all finite (Java's Math.min / max
-         // treat NaN specially; the host builder restates that, the GPU's integer-key min / max do not).
-         bool gpu_build = allow_gpu_build && bo.use_kdtree && bo.max_depth >= 1 && md.n_faces > (uint32_t) std::max(bo.max_children, 0) &&
-                          md.vertices && md.indices;
-         for (size_t v = 0; gpu_build && v < 3 * (size_t) md.n_vertices; v++) gpu_build = std::isfinite(md.vertices[v]);
-         BuildOptions bo_obj = bo;
-         bo_obj.build_tree = !gpu_build;
-         BuiltObject bo_out;
-         const auto t_prep = std::chrono::steady_clock::now();
-         const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo_obj, bo_out);
-         if (!err.empty()) {
-            free_parts();
-            release_scene(s);
-            return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
-         }
-         const size_t node_base = node_total, slot_base = slot_total, face_base = face_total;
-         uint64_t n_leaves = bo_out.n_leaves;
-         int32_t tree_depth = bo_out.max_depth;
-         const auto t_tree = std::chrono::steady_clock::now();
-         if (gpu_build) {
-            std::string gerr;
-            const hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj, part.gpu, gerr);
-            if (ge != hipSuccess) {
+            const size_t node_base = node_total, slot_base = slot_total, face_base = face_total;
+            uint64_t n_leaves = bo_out.n_leaves;
+            int32_t tree_depth = bo_out.max_depth;
+            const auto t_tree = std::chrono::steady_clock::now();
+            if (gpu_build) {
+               std::string gerr;
+               const hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj, part.gpu, gerr);
+               if (ge != hipSuccess) {
+                  free_parts();
+                  release_scene(s);
+                  if (!gerr.empty()) return fail(MI355RT_E_LIMIT, "mesh " + std::to_string(i) + ": " + gerr);
+                  return hip_fail(ge, "GPU hierarchy build");
+               }
+               part.on_gpu = true;
+               s->any_gpu_build = true;
+               part.n_nodes = (size_t) part.gpu.n_nodes;
+               part.n_slots = (size_t) part.gpu.n_slots;
+               n_leaves = part.gpu.n_leaves;
+               tree_depth = part.gpu.max_depth;
+            } else {
+               part.n_nodes = bo_out.nodes.size();
+               part.n_slots = bo_out.slot_face.size();
+            }
+            part.node_base = node_base;
+            part.slot_base = slot_base;
+            if (node_base + part.n_nodes > (size_t) 0x7ffffff0 || slot_base + part.n_slots > (size_t) 0x7ffffff0 ||
+                face_base + md.n_faces > (size_t) 0x7ffffff0) {
                free_parts();
                release_scene(s);
-               if (!gerr.empty()) return fail(MI355RT_E_LIMIT, "mesh " + std::to_string(i) + ": " + gerr);
-               return hip_fail(ge, "GPU hierarchy build");
+               return fail(MI355RT_E_LIMIT, "scene exceeds 2^31 nodes, leaf slots or faces");
             }
-            part.on_gpu = true;
-            s->any_gpu_build = true;
-            part.n_nodes = (size_t) part.gpu.n_nodes;
-            part.n_slots = (size_t) part.gpu.n_slots;
-            n_leaves = part.gpu.n_leaves;
-            tree_depth = part.gpu.max_depth;
-         } else {
-            part.n_nodes = bo_out.nodes.size();
-            part.n_slots = bo_out.slot_face.size();
-         }
-         part.node_base = node_base;
-         part.slot_base = slot_base;
-         if (node_base + part.n_nodes > (size_t) 0x7ffffff0 || slot_base + part.n_slots > (size_t) 0x7ffffff0 ||
-             face_base + md.n_faces > (size_t) 0x7ffffff0) {
-            free_parts();
-            release_scene(s);
-            return fail(MI355RT_E_LIMIT, "scene exceeds 2^31 nodes, leaf slots or faces");
-         }
-         if (!gpu_build) host_part_records(bo_out, md, part, boxes_finite);
-         node_total += part.n_nodes;
-         slot_total += part.n_slots;
-         if (getenv("MI355RT_BUILD_TIMING")) {   // profiling aid
-            const auto t_end = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + normals + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
-                         gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
-                         gpu_build ? "GPU hierarchy" : "records", std::chrono::duration<double>(t_end - t_tree).count());
-         }
-         append_face_normals(all_fnrm, face_base, md, bo_out.normals);
-         face_total += md.n_faces;
+            if (!gpu_build) host_part_records(bo_out, md, part, boxes_finite);
+            node_total += part.n_nodes;
+            slot_total += part.n_slots;
+            if (getenv("MI355RT_BUILD_TIMING")) {   // profiling aid
+               const auto t_end = std::chrono::steady_clock::now();
+               std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + normals + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
+                            gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
+                            gpu_build ? "GPU hierarchy" : "records", std::chrono::duration<double>(t_end - t_tree).count());
+            }
+            append_face_normals(all_fnrm, face_base, md, bo_out.normals);
+            face_total += md.n_faces;
 
-         s->objects.emplace_back();
-         s->materials.push_back(md.material);
-         for (size_t v = 0; v + 2 < bo_out.normals.size(); v += 3) {
-            const float *nv = bo_out.normals.data() + v;
-            const float len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-            if (!(len <= s->max_normal_len)) s->max_normal_len = len;   // a NaN length sticks (and disables the any-hit shortcut)
+            s->objects.emplace_back();
+            s->materials.push_back(md.material);
+            for (size_t v = 0; v + 2 < bo_out.normals.size(); v += 3) {
+               const float *nv = bo_out.normals.data() + v;
+               const float len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+               if (!(len <= s->max_normal_len)) s->max_normal_len = len;   // a NaN length sticks (and disables the any-hit shortcut)
+            }
+            HostObject &ho = s->objects.back();
+            std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
+            std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
+            ho.shadow_distance = bo_out.shadow_distance;
+            ho.n_nodes = part.n_nodes;
+            ho.n_leaves = n_leaves;
+            ho.n_slots = part.n_slots;
+            ho.max_depth = tree_depth;
+            ho.is_mesh = true;
+            DevObject &d = dev_objs[i];
+            d.kind = OBJ_MESH;
+            std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
+            std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
+            d.root_entry = (gpu_build || !bo_out.root_is_leaf) ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
+            d.shadow_distance = bo_out.shadow_distance;
+            d.face_base = (int32_t) face_base;
+            d.node_base = (int32_t) node_base;
+            d.slot_base = (int32_t) slot_base;
+            set_material(d, md.material);
          }
-         HostObject &ho = s->objects.back();
-         std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
-         std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
-         ho.shadow_distance = bo_out.shadow_distance;
-         ho.n_nodes = part.n_nodes;
-         ho.n_leaves = n_leaves;
-         ho.n_slots = part.n_slots;
-         ho.max_depth = tree_depth;
-         ho.is_mesh = true;
-         DevObject &d = dev_objs[i];
-         d.kind = OBJ_MESH;
-         std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
-         std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
-         d.root_entry = (gpu_build || !bo_out.root_is_leaf) ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
-         d.shadow_distance = bo_out.shadow_distance;
-         d.face_base = (int32_t) face_base;
-         d.node_base = (int32_t) node_base;
-         d.slot_base = (int32_t) slot_base;
-         set_material(d, md.material);
-      }
-      for (const HostObject &ho : s->objects) {   // Scene.java:21-33
-         for (int c = 0; c < 3; c++) {
-            s->smin[c] = jm::fmin_java(s->smin[c], ho.bmin[c]);
-            s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
+         for (const HostObject &ho : s->objects) {   // Scene.java:21-33
+            for (int c = 0; c < 3; c++) {
+               s->smin[c] = jm::fmin_java(s->smin[c], ho.bmin[c]);
+               s->smax[c] = jm::fmax_java(s->smax[c], ho.bmax[c]);
+            }
          }
-      }
-   } catch (const std::bad_alloc &) {
-      free_parts();
-      release_scene(s);
-      return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
-   }
-   {
-      const hipError_t e = upload_parts(s, parts, node_total, slot_total);
-      free_parts();
-      if (e != hipSuccess) {
+      } catch (const std::bad_alloc &) {
+         free_parts();
          release_scene(s);
-         return hip_fail(e, "hierarchy upload");
+         return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
       }
-      s->n_fnrm_floats = all_fnrm.size();
-      if (int rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s)) {
+      {
+         const hipError_t e = upload_parts(s, parts, node_total, slot_total);
+         free_parts();
+         if (e != hipSuccess) {
+            release_scene(s);
+            return hip_fail(e, "hierarchy upload");
+         }
+         s->n_fnrm_floats = all_fnrm.size();
+         if (int rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s)) {
+            release_scene(s);
+            return rc;
+         }
+      }
+      float amax = 0.f;
+      for (int c = 0; c < 3; c++) {
+         if (std::isfinite(s->smin[c])) amax = std::fmax(amax, std::fabs(s->smin[c]));
+         if (std::isfinite(s->smax[c])) amax = std::fmax(amax, std::fabs(s->smax[c]));
+      }
+      s->abs_max = n_meshes ? amax : 0.f;
+      s->boxes_finite = boxes_finite;
+      int rc;
+      if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s)) ||
+          (rc = upload(dev_ext.data(), sizeof(DevObjectExt) * dev_ext.size(), (void **) &s->d_ext, s))) {
          release_scene(s);
          return rc;
       }
-   }
-   float amax = 0.f;
-   for (int c = 0; c < 3; c++) {
-      if (std::isfinite(s->smin[c])) amax = std::fmax(amax, std::fabs(s->smin[c]));
-      if (std::isfinite(s->smax[c])) amax = std::fmax(amax, std::fabs(s->smax[c]));
-   }
-   s->abs_max = n_meshes ? amax : 0.f;
-   s->boxes_finite = boxes_finite;
-   int rc;
-   if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s)) ||
-       (rc = upload(dev_ext.data(), sizeof(DevObjectExt) * dev_ext.size(), (void **) &s->d_ext, s))) {
-      release_scene(s);
-      return rc;
-   }
-   hipError_t e = hipMalloc((void **) &s->d_counters, CNT_WORDS * sizeof(uint32_t));
-   if (e == hipSuccess) e = hipHostMalloc((void **) &s->h_readback, N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
-   if (e != hipSuccess) {
-      release_scene(s);
-      return hip_fail(e, "hipMalloc(counters)");
-   }
-   // set-up for mi355rt_render_device_noalloc: this device's address of the static scratch array, while the device is current
-   e = noalloc_scratch_ptr(device, &s->noalloc_scratch);
-   if (e != hipSuccess) {
-      release_scene(s);
-      return hip_fail(e, "hipGetSymbolAddress(scratch)");
-   }
-   int cus = 0;
-   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
-   *out = s;
-   return MI355RT_OK;
+      hipError_t e = hipMalloc((void **) &s->d_counters, CNT_WORDS * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipHostMalloc((void **) &s->h_readback, N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
+      if (e != hipSuccess) {
+         release_scene(s);
+         return hip_fail(e, "hipMalloc(counters)");
+      }
+      // set-up for mi355rt_render_device_noalloc: this device's address of the static scratch array, while the device is current
+      e = noalloc_scratch_ptr(device, &s->noalloc_scratch);
+      if (e != hipSuccess) {
+         release_scene(s);
+         return hip_fail(e, "hipGetSymbolAddress(scratch)");
+      }
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
+      guard.s = nullptr;
+      *out = s;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts, mi355rt_scene **out)
 {
-   if (!out) return fail(MI355RT_E_ARG, "out is null");
-   *out = nullptr;
-   if (n_meshes && !meshes) return fail(MI355RT_E_ARG, "meshes is null");
-   for (uint32_t i = 0; i < n_meshes; i++) {
-      if (meshes[i].material.kind > MI355RT_MAT_REFLECTION) return fail(MI355RT_E_ARG, "unknown material kind on mesh " + std::to_string(i));
-   }
-   std::vector<mi355rt_object_desc> objects(n_meshes ? n_meshes : 1);
-   std::memset(objects.data(), 0, sizeof(mi355rt_object_desc) * objects.size());
-   for (uint32_t i = 0; i < n_meshes; i++) {
-      objects[i].kind = MI355RT_OBJ_MESH;
-      objects[i].mesh = meshes[i];
-   }
-   return mi355rt_scene_create_objects(objects.data(), n_meshes, opts, out);
+   return guarded([&]() -> int {
+      if (!out) return fail(MI355RT_E_ARG, "out is null");
+      *out = nullptr;
+      if (n_meshes && !meshes) return fail(MI355RT_E_ARG, "meshes is null");
+      for (uint32_t i = 0; i < n_meshes; i++) {
+         if (meshes[i].material.kind > MI355RT_MAT_REFLECTION) return fail(MI355RT_E_ARG, "unknown material kind on mesh " + std::to_string(i));
+      }
+      std::vector<mi355rt_object_desc> objects(n_meshes ? n_meshes : 1);
+      std::memset(objects.data(), 0, sizeof(mi355rt_object_desc) * objects.size());
+      for (uint32_t i = 0; i < n_meshes; i++) {
+         objects[i].kind = MI355RT_OBJ_MESH;
+         objects[i].mesh = meshes[i];
+      }
+      return mi355rt_scene_create_objects(objects.data(), n_meshes, opts, out);
+   });
 }
 
 void mi355rt_scene_destroy(mi355rt_scene *scene)
 {
    if (!scene) return;
    DeviceScope scope(scene->device);
-   release_scene(scene);
+   release_scene_impl(scene);
 }
 
 int mi355rt_brdf_tables(mi355rt_scene *scene, const float *angles, int32_t n_dirs, const float *weights, int32_t n_materials)
 {
-   if (!scene || !angles || !weights) return fail(MI355RT_E_ARG, "null argument");
-   if (n_dirs < 1 || n_materials < 1) return fail(MI355RT_E_ARG, "table sizes must be positive");
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   // BRDFMaterial.remapDirections -> PBRTMath.getRemappedDirection(float[], float[]) PBRTMath.java:74-97
-   const float f_pi = (float) jm::kPi, f_2pi = 2.0f * (float) jm::kPi;
-   std::vector<float> dirs(3 * (size_t) n_dirs);
-   for (int32_t i = 0; i < n_dirs; i++) {
-      const float theta_v = angles[4 * i], phi_v = angles[4 * i + 1], theta_i = angles[4 * i + 2], phi_i = angles[4 * i + 3];
-      const float cosi = (float) std::cos((double) theta_v), coso = (float) std::cos((double) theta_i);
-      const float sini = (float) std::sin((double) theta_v), sino = (float) std::sin((double) theta_i);
-      const float phii = ((double) phi_v < jm::kPi / 2.0f) ? phi_v + 2.0f * f_pi : phi_v;   // PBRTMath.normalizePhi
-      const float phio = ((double) phi_i < jm::kPi / 2.0f) ? phi_i + 2.0f * f_pi : phi_i;
-      float dphi = phii - phio;
-      if (dphi < 0.0f) dphi += f_2pi;
-      if (dphi > f_2pi) dphi -= f_2pi;
-      if (dphi > f_pi) dphi = f_2pi - dphi;
-      dirs[3 * (size_t) i + 0] = sini * sino;
-      dirs[3 * (size_t) i + 1] = dphi / f_pi;
-      dirs[3 * (size_t) i + 2] = cosi * coso;
-   }
-   if (scene->d_brdf_dirs) (void) hipFree(scene->d_brdf_dirs);
-   if (scene->d_brdf_weights) (void) hipFree(scene->d_brdf_weights);
-   scene->d_brdf_dirs = scene->d_brdf_weights = nullptr;
-   scene->n_dirs = scene->n_materials = 0;
-   int rc;
-   if ((rc = upload(dirs.data(), dirs.size() * sizeof(float), (void **) &scene->d_brdf_dirs, scene))) return rc;
-   if ((rc = upload(weights, sizeof(float) * (size_t) n_dirs * (size_t) n_materials, (void **) &scene->d_brdf_weights, scene))) return rc;
-   scene->n_dirs = n_dirs;
-   scene->n_materials = n_materials;
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !angles || !weights) return fail(MI355RT_E_ARG, "null argument");
+      if (n_dirs < 1 || n_materials < 1) return fail(MI355RT_E_ARG, "table sizes must be positive");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      // BRDFMaterial.remapDirections -> PBRTMath.getRemappedDirection(float[], float[]) PBRTMath.java:74-97
+      const float f_pi = (float) jm::kPi, f_2pi = 2.0f * (float) jm::kPi;
+      std::vector<float> dirs(3 * (size_t) n_dirs);
+      for (int32_t i = 0; i < n_dirs; i++) {
+         const float theta_v = angles[4 * i], phi_v = angles[4 * i + 1], theta_i = angles[4 * i + 2], phi_i = angles[4 * i + 3];
+         const float cosi = (float) std::cos((double) theta_v), coso = (float) std::cos((double) theta_i);
+         const float sini = (float) std::sin((double) theta_v), sino = (float) std::sin((double) theta_i);
+         const float phii = ((double) phi_v < jm::kPi / 2.0f) ? phi_v + 2.0f * f_pi : phi_v;   // PBRTMath.normalizePhi
+         const float phio = ((double) phi_i < jm::kPi / 2.0f) ? phi_i + 2.0f * f_pi : phi_i;
+         float dphi = phii - phio;
+         if (dphi < 0.0f) dphi += f_2pi;
+         if (dphi > f_2pi) dphi -= f_2pi;
+         if (dphi > f_pi) dphi = f_2pi - dphi;
+         dirs[3 * (size_t) i + 0] = sini * sino;
+         dirs[3 * (size_t) i + 1] = dphi / f_pi;
+         dirs[3 * (size_t) i + 2] = cosi * coso;
+      }
+      if (scene->d_brdf_dirs) (void) hipFree(scene->d_brdf_dirs);
+      if (scene->d_brdf_weights) (void) hipFree(scene->d_brdf_weights);
+      scene->d_brdf_dirs = scene->d_brdf_weights = nullptr;
+      scene->n_dirs = scene->n_materials = 0;
+      int rc;
+      if ((rc = upload(dirs.data(), dirs.size() * sizeof(float), (void **) &scene->d_brdf_dirs, scene))) return rc;
+      if ((rc = upload(weights, sizeof(float) * (size_t) n_dirs * (size_t) n_materials, (void **) &scene->d_brdf_weights, scene))) return rc;
+      scene->n_dirs = n_dirs;
+      scene->n_materials = n_materials;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_scene_epsilon(const mi355rt_scene *scene, float *epsilon_out)
 {
-   if (!scene || !epsilon_out) return fail(MI355RT_E_ARG, "null argument");
-   const float span = jm::fmax_java(scene->smax[0] - scene->smin[0],
-                                    jm::fmax_java(scene->smax[1] - scene->smin[1], scene->smax[2] - scene->smin[2]));
-   *epsilon_out = (span < 10) ? 1e-15f : 1e-3f;   // Scene.java:35-36
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !epsilon_out) return fail(MI355RT_E_ARG, "null argument");
+      const float span = jm::fmax_java(scene->smax[0] - scene->smin[0],
+                                       jm::fmax_java(scene->smax[1] - scene->smin[1], scene->smax[2] - scene->smin[2]));
+      *epsilon_out = (span < 10) ? 1e-15f : 1e-3f;   // Scene.java:35-36
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_scene_object_info(const mi355rt_scene *scene, uint32_t object, float minmax[6], float *shadow_distance,
                               uint64_t *n_nodes, uint64_t *n_leaves, uint64_t *n_leaf_slots, int32_t *max_depth)
 {
-   if (!scene) return fail(MI355RT_E_ARG, "scene is null");
-   if (object >= scene->objects.size()) return fail(MI355RT_E_ARG, "object index out of range");
-   const HostObject &o = scene->objects[object];
-   if (minmax) {
-      std::memcpy(minmax, o.bmin, sizeof(o.bmin));
-      std::memcpy(minmax + 3, o.bmax, sizeof(o.bmax));
-   }
-   if (shadow_distance) *shadow_distance = o.shadow_distance;
-   if (n_nodes) *n_nodes = o.n_nodes;
-   if (n_leaves) *n_leaves = o.n_leaves;
-   if (n_leaf_slots) *n_leaf_slots = o.n_slots;
-   if (max_depth) *max_depth = o.max_depth;
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene) return fail(MI355RT_E_ARG, "scene is null");
+      if (object >= scene->objects.size()) return fail(MI355RT_E_ARG, "object index out of range");
+      const HostObject &o = scene->objects[object];
+      if (minmax) {
+         std::memcpy(minmax, o.bmin, sizeof(o.bmin));
+         std::memcpy(minmax + 3, o.bmax, sizeof(o.bmax));
+      }
+      if (shadow_distance) *shadow_distance = o.shadow_distance;
+      if (n_nodes) *n_nodes = o.n_nodes;
+      if (n_leaves) *n_leaves = o.n_leaves;
+      if (n_leaf_slots) *n_leaf_slots = o.n_slots;
+      if (max_depth) *max_depth = o.max_depth;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_scene_device_bytes(const mi355rt_scene *scene, uint64_t *bytes_out)
 {
-   if (!scene || !bytes_out) return fail(MI355RT_E_ARG, "null argument");
-   *bytes_out = scene->device_bytes;
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !bytes_out) return fail(MI355RT_E_ARG, "null argument");
+      *bytes_out = scene->device_bytes;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_camera_setup(const mi355rt_scene *scene, const float orientation_deg[3], float fov_deg, float near_plane, int32_t width,
                          int32_t height, mi355rt_camera *out)
 {
-   if (!scene || !orientation_deg || !out) return fail(MI355RT_E_ARG, "null argument");
-   if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
-   out->near_plane = near_plane;
-   out->width = width;
-   out->height = height;
-   // Camera.java:50-51
-   out->viewport_w = (width >= height ? (float) width / (float) height : 1.0f) * near_plane;
-   out->viewport_h = (width >= height ? 1.0f : (float) height / (float) width) * near_plane;
-   // RTStatics.initializeQuat4f(float[]) RTStatics.java:345-354: yaw(-o0) * pitch(o1) * roll(-o2)
-   const jm::Quat yaw = jm::quat_from_axis_angle({ 0.f, 1.f, 0.f }, -orientation_deg[0]);
-   const jm::Quat pitch = jm::quat_from_axis_angle({ 1.f, 0.f, 0.f }, orientation_deg[1]);
-   const jm::Quat roll = jm::quat_from_axis_angle({ 0.f, 0.f, 1.f }, -orientation_deg[2]);
-   jm::quat_to_rows(jm::quat_mul(jm::quat_mul(yaw, pitch), roll), out->rotation);
-   // Camera.java:72-81
-   const float w = scene->smax[0] - scene->smin[0];
-   const float h = scene->smax[1] - scene->smin[1];
-   const float d = scene->smax[2] - scene->smin[2];
-   const float cx = w / 2.0f + scene->smin[0];
-   const float cy = h / 2.0f + scene->smin[1];
-   const float cz = d / 2.0f + scene->smin[2];
-   const float distance = w / 2.0f / (float) std::tan(jm::to_radians((double) fov_deg));
-   const jm::Vec3 o = jm::rotate(out->rotation, { cx, cy, cz + distance });
-   out->origin[0] = o.x;
-   out->origin[1] = o.y;
-   out->origin[2] = o.z;
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !orientation_deg || !out) return fail(MI355RT_E_ARG, "null argument");
+      if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+      out->near_plane = near_plane;
+      out->width = width;
+      out->height = height;
+      // Camera.java:50-51
+      out->viewport_w = (width >= height ? (float) width / (float) height : 1.0f) * near_plane;
+      out->viewport_h = (width >= height ? 1.0f : (float) height / (float) width) * near_plane;
+      // RTStatics.initializeQuat4f(float[]) RTStatics.java:345-354: yaw(-o0) * pitch(o1) * roll(-o2)
+      const jm::Quat yaw = jm::quat_from_axis_angle({ 0.f, 1.f, 0.f }, -orientation_deg[0]);
+      const jm::Quat pitch = jm::quat_from_axis_angle({ 1.f, 0.f, 0.f }, orientation_deg[1]);
+      const jm::Quat roll = jm::quat_from_axis_angle({ 0.f, 0.f, 1.f }, -orientation_deg[2]);
+      jm::quat_to_rows(jm::quat_mul(jm::quat_mul(yaw, pitch), roll), out->rotation);
+      // Camera.java:72-81
+      const float w = scene->smax[0] - scene->smin[0];
+      const float h = scene->smax[1] - scene->smin[1];
+      const float d = scene->smax[2] - scene->smin[2];
+      const float cx = w / 2.0f + scene->smin[0];
+      const float cy = h / 2.0f + scene->smin[1];
+      const float cz = d / 2.0f + scene->smin[2];
+      const float distance = w / 2.0f / (float) std::tan(jm::to_radians((double) fov_deg));
+      const jm::Vec3 o = jm::rotate(out->rotation, { cx, cy, cz + distance });
+      out->origin[0] = o.x;
+      out->origin[1] = o.y;
+      out->origin[2] = o.z;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_frame *frame,
                           void *hip_stream)
 {
-   if (!scene || !frame) return fail(MI355RT_E_ARG, "null argument");
-   FrameArgs p;
-   long long n_micro = 0;
-   if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   p.rgb = frame->rgb;
-   p.argb8 = frame->argb8;
-   p.hit_id = frame->hit_id;
-   p.hit_obj = frame->hit_obj;
-   p.hit_w = frame->hit_w;
-   return run_frame(scene, p, n_micro, (settings->collect_stats & MI355RT_COLLECT_TIMES) != 0, (hipStream_t) hip_stream);
+   return guarded([&]() -> int {
+      if (!scene || !frame) return fail(MI355RT_E_ARG, "null argument");
+      FrameArgs p;
+      long long n_micro = 0;
+      if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      p.rgb = frame->rgb;
+      p.argb8 = frame->argb8;
+      p.hit_id = frame->hit_id;
+      p.hit_obj = frame->hit_obj;
+      p.hit_w = frame->hit_w;
+      return run_frame(scene, p, n_micro, (settings->collect_stats & MI355RT_COLLECT_TIMES) != 0, (hipStream_t) hip_stream);
+   });
 }
 
 int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_frame *frame,
                                   void *hip_stream)
 {
-   if (!scene || !frame || !settings) return fail(MI355RT_E_ARG, "null argument");
-   if (settings->collect_stats != 0) return fail(MI355RT_E_ARG, "mi355rt_render_device_noalloc takes collect_stats == 0 (counting and timing create events and read back)");
-   FrameArgs p;
-   long long n_micro = 0;
-   if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   unsigned char *base = (unsigned char *) scene->noalloc_scratch;   // resolved at scene creation (hipGetSymbolAddress), per device
-   if (!base) return fail(MI355RT_E_DEVICE, "the static scratch array was not resolved on this device");
-   // the whole frame is one pass: every band's sub-queue of every record array must fit the array
-   const bool with_mirror = scene->has_mirror || scene->has_refraction, with_refraction = scene->has_refraction;
-   const unsigned long long slots = (unsigned long long) ((n_micro + N_BANDS - 1) / N_BANDS) * N_BANDS * 64ull * (unsigned long long) settings->multi_samples;
-   const unsigned long long per_slot = 104ull + (with_mirror ? 100ull : 0ull) + (with_refraction ? 16ull * (1 + MAX_REFRACTION_TERMS) : 0ull);
-   constexpr unsigned long long HEAD = 4096, ALIGN_SLACK = 12 * 256;   // counters; each of up to 12 arrays starts on a 256-byte boundary
-   if (slots * per_slot + HEAD + ALIGN_SLACK > (unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES)
-      return fail(MI355RT_E_LIMIT, "mi355rt_render_device_noalloc: " + std::to_string(slots) + " sample slots x " + std::to_string(per_slot) +
-                                       " bytes exceed the static scratch of " + std::to_string((unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES) +
-                                       " bytes; use mi355rt_render_device for this frame");
-   static_assert(CNT_WORDS * sizeof(uint32_t) <= 4096, "the counter block sits in the first 4 KiB of the scratch");
-   FrameScratch fs;
-   size_t off = HEAD;
-   auto carve = [&](size_t bytes) -> void * {
-      void *q = base + off;
-      off = (off + bytes + 255) & ~(size_t) 255;
-      return q;
-   };
-   fs.cap = (size_t) slots;
-   fs.with_mirror = with_mirror;
-   fs.with_refraction = with_refraction;
-   fs.samples = (float *) carve(slots * 16);
-   fs.rays0 = (float *) carve(slots * 32);
-   fs.hits0 = (float *) carve(slots * 32);
-   fs.mat0 = (float *) carve(slots * 16);
-   fs.hit_obj0 = (int32_t *) carve(slots * 4);
-   fs.shadow = (uint32_t *) carve(slots * 4);
-   if (with_mirror) {
-      fs.rays1[0] = (float *) carve(slots * 32);
-      fs.rays1[1] = (float *) carve(slots * 32);
-      fs.hits1 = (float *) carve(slots * 32);
-      fs.hit_obj1 = (int32_t *) carve(slots * 4);
-   }
-   if (with_refraction) {
-      fs.refr_parent = (float *) carve(slots * 16);
-      fs.refr_terms = (float *) carve(slots * 16 * MAX_REFRACTION_TERMS);
-   }
-   p.rgb = frame->rgb;
-   p.argb8 = frame->argb8;
-   p.hit_id = frame->hit_id;
-   p.hit_obj = frame->hit_obj;
-   p.hit_w = frame->hit_w;
-   // the array keeps the previous call's contents: run_frame clears the counter block at the start of the pass (the
-   // only part that must start at zero); every queue record is written before it is read
-   return run_frame(scene, p, n_micro, false, (hipStream_t) hip_stream, &fs, (uint32_t *) base);
+   return guarded([&]() -> int {
+      if (!scene || !frame || !settings) return fail(MI355RT_E_ARG, "null argument");
+      if (settings->collect_stats != 0) return fail(MI355RT_E_ARG, "mi355rt_render_device_noalloc takes collect_stats == 0 (counting and timing create events and read back)");
+      FrameArgs p;
+      long long n_micro = 0;
+      if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      unsigned char *base = (unsigned char *) scene->noalloc_scratch;   // resolved at scene creation (hipGetSymbolAddress), per device
+      if (!base) return fail(MI355RT_E_DEVICE, "the static scratch array was not resolved on this device");
+      // the whole frame is one pass: every band's sub-queue of every record array must fit the array
+      const bool with_mirror = scene->has_mirror || scene->has_refraction, with_refraction = scene->has_refraction;
+      const unsigned long long slots = (unsigned long long) ((n_micro + N_BANDS - 1) / N_BANDS) * N_BANDS * 64ull * (unsigned long long) settings->multi_samples;
+      const unsigned long long per_slot = 104ull + (with_mirror ? 100ull : 0ull) + (with_refraction ? 16ull * (1 + MAX_REFRACTION_TERMS) : 0ull);
+      constexpr unsigned long long HEAD = 4096, ALIGN_SLACK = 12 * 256;   // counters; each of up to 12 arrays starts on a 256-byte boundary
+      if (slots * per_slot + HEAD + ALIGN_SLACK > (unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES)
+         return fail(MI355RT_E_LIMIT, "mi355rt_render_device_noalloc: " + std::to_string(slots) + " sample slots x " + std::to_string(per_slot) +
+                                          " bytes exceed the static scratch of " + std::to_string((unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES) +
+                                          " bytes; use mi355rt_render_device for this frame");
+      static_assert(CNT_WORDS * sizeof(uint32_t) <= 4096, "the counter block sits in the first 4 KiB of the scratch");
+      FrameScratch fs;
+      size_t off = HEAD;
+      auto carve = [&](size_t bytes) -> void * {
+         void *q = base + off;
+         off = (off + bytes + 255) & ~(size_t) 255;
+         return q;
+      };
+      fs.cap = (size_t) slots;
+      fs.with_mirror = with_mirror;
+      fs.with_refraction = with_refraction;
+      fs.samples = (float *) carve(slots * 16);
+      fs.rays0 = (float *) carve(slots * 32);
+      fs.hits0 = (float *) carve(slots * 32);
+      fs.mat0 = (float *) carve(slots * 16);
+      fs.hit_obj0 = (int32_t *) carve(slots * 4);
+      fs.shadow = (uint32_t *) carve(slots * 4);
+      if (with_mirror) {
+         fs.rays1[0] = (float *) carve(slots * 32);
+         fs.rays1[1] = (float *) carve(slots * 32);
+         fs.hits1 = (float *) carve(slots * 32);
+         fs.hit_obj1 = (int32_t *) carve(slots * 4);
+      }
+      if (with_refraction) {
+         fs.refr_parent = (float *) carve(slots * 16);
+         fs.refr_terms = (float *) carve(slots * 16 * MAX_REFRACTION_TERMS);
+      }
+      p.rgb = frame->rgb;
+      p.argb8 = frame->argb8;
+      p.hit_id = frame->hit_id;
+      p.hit_obj = frame->hit_obj;
+      p.hit_w = frame->hit_w;
+      // the array keeps the previous call's contents: run_frame clears the counter block at the start of the pass (the
+      // only part that must start at zero); every queue record is written before it is read
+      return run_frame(scene, p, n_micro, false, (hipStream_t) hip_stream, &fs, (uint32_t *) base);
+   });
 }
 
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
-                   int32_t *hit_id_out, float *hit_w_out)
+                   int32_t *hit_id_out, int32_t *hit_obj_out, float *hit_w_out)
 {
-   if (!scene || !cam) return fail(MI355RT_E_ARG, "null argument");
-   if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   const size_t pixels = (size_t) cam->width * (size_t) cam->height;
-   if (pixels > scene->frame_pixels) {
-      if (scene->d_rgb) (void) hipFree(scene->d_rgb);
-      if (scene->d_hit_id) (void) hipFree(scene->d_hit_id);
-      if (scene->d_hit_w) (void) hipFree(scene->d_hit_w);
-      scene->d_rgb = nullptr;
-      scene->d_hit_id = nullptr;
-      scene->d_hit_w = nullptr;
-      scene->frame_pixels = 0;
-      HIP_TRY(hipMalloc((void **) &scene->d_rgb, pixels * 3 * sizeof(float)));
-      HIP_TRY(hipMalloc((void **) &scene->d_hit_id, pixels * sizeof(int32_t)));
-      HIP_TRY(hipMalloc((void **) &scene->d_hit_w, pixels * sizeof(float)));
-      scene->frame_pixels = pixels;
-   }
-   // tiles owned by other ranks stay zero
-   HIP_TRY(hipMemsetAsync(scene->d_rgb, 0, pixels * 3 * sizeof(float), nullptr));
-   HIP_TRY(hipMemsetAsync(scene->d_hit_id, 0, pixels * sizeof(int32_t), nullptr));
-   HIP_TRY(hipMemsetAsync(scene->d_hit_w, 0, pixels * sizeof(float), nullptr));
-   mi355rt_frame fr;
-   std::memset(&fr, 0, sizeof(fr));
-   fr.rgb = scene->d_rgb;
-   fr.hit_id = scene->d_hit_id;
-   fr.hit_w = scene->d_hit_w;
-   if (int rc = mi355rt_render_device(scene, cam, settings, &fr, nullptr)) return rc;
-   HIP_TRY(hipStreamSynchronize(nullptr));
-   if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, scene->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
-   if (hit_id_out) HIP_TRY(hipMemcpy(hit_id_out, scene->d_hit_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
-   if (hit_w_out) HIP_TRY(hipMemcpy(hit_w_out, scene->d_hit_w, pixels * sizeof(float), hipMemcpyDeviceToHost));
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !cam || !settings) return fail(MI355RT_E_ARG, "null argument");
+      if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      const size_t pixels = (size_t) cam->width * (size_t) cam->height;
+      if (pixels > scene->frame_pixels) {
+         void **all[] = { (void **) &scene->d_rgb, (void **) &scene->d_hit_id, (void **) &scene->d_hit_obj, (void **) &scene->d_hit_w };
+         for (void **q : all) {
+            if (*q) (void) hipFree(*q);
+            *q = nullptr;
+         }
+         scene->frame_pixels = 0;
+         HIP_TRY(hipMalloc((void **) &scene->d_rgb, pixels * 3 * sizeof(float)));
+         HIP_TRY(hipMalloc((void **) &scene->d_hit_id, pixels * sizeof(int32_t)));
+         HIP_TRY(hipMalloc((void **) &scene->d_hit_obj, pixels * sizeof(int32_t)));
+         HIP_TRY(hipMalloc((void **) &scene->d_hit_w, pixels * sizeof(float)));
+         scene->frame_pixels = pixels;
+      }
+      if (settings->tile_world > 1) {   // tiles owned by other ranks stay zero
+         HIP_TRY(hipMemsetAsync(scene->d_rgb, 0, pixels * 3 * sizeof(float), nullptr));
+         HIP_TRY(hipMemsetAsync(scene->d_hit_id, 0, pixels * sizeof(int32_t), nullptr));
+         HIP_TRY(hipMemsetAsync(scene->d_hit_obj, 0, pixels * sizeof(int32_t), nullptr));
+         HIP_TRY(hipMemsetAsync(scene->d_hit_w, 0, pixels * sizeof(float), nullptr));
+      }
+      mi355rt_frame fr;
+      std::memset(&fr, 0, sizeof(fr));
+      fr.rgb = rgb_out ? scene->d_rgb : nullptr;   // an output nobody asked for is not written either
+      fr.hit_id = hit_id_out ? scene->d_hit_id : nullptr;
+      fr.hit_obj = hit_obj_out ? scene->d_hit_obj : nullptr;
+      fr.hit_w = hit_w_out ? scene->d_hit_w : nullptr;
+      if (int rc = mi355rt_render_device(scene, cam, settings, &fr, nullptr)) return rc;
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, scene->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+      if (hit_id_out) HIP_TRY(hipMemcpy(hit_id_out, scene->d_hit_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (hit_obj_out) HIP_TRY(hipMemcpy(hit_obj_out, scene->d_hit_obj, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
+      if (hit_w_out) HIP_TRY(hipMemcpy(hit_w_out, scene->d_hit_w, pixels * sizeof(float), hipMemcpyDeviceToHost));
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_host_alloc(uint64_t bytes, void **ptr_out)
 {
-   if (!ptr_out || !bytes) return fail(MI355RT_E_ARG, "null pointer or zero size");
-   *ptr_out = nullptr;
-   HIP_TRY(hipHostMalloc(ptr_out, (size_t) bytes, hipHostMallocDefault));
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!ptr_out || !bytes) return fail(MI355RT_E_ARG, "null pointer or zero size");
+      *ptr_out = nullptr;
+      HIP_TRY(hipHostMalloc(ptr_out, (size_t) bytes, hipHostMallocDefault));
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_host_free(void *ptr)
 {
-   if (!ptr) return MI355RT_OK;
-   HIP_TRY(hipHostFree(ptr));
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!ptr) return MI355RT_OK;
+      HIP_TRY(hipHostFree(ptr));
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
 {
-   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
-   if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
-   *out = scene->stats_accum;   // run_frame reads the counters back at the end of each pass
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
+      *out = scene->stats_accum;   // run_frame reads the counters back at the end of each pass
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_image_argb8_device(const float *rgb_dev, int32_t width, int32_t height, int normalized, uint32_t *argb_dev,
                                uint32_t *minmax_scratch, void *hip_stream)
 {
-   if (!rgb_dev || !argb_dev || (normalized && !minmax_scratch)) return fail(MI355RT_E_ARG, "null argument");
-   if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
-   int device = 0, cus = 256;
-   HIP_TRY(hipGetDevice(&device));
-   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
-   HIP_TRY(launch_image(rgb_dev, (unsigned long long) width * (unsigned long long) height, normalized, minmax_scratch, argb_dev, cus,
-                        (hipStream_t) hip_stream));
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!rgb_dev || !argb_dev || (normalized && !minmax_scratch)) return fail(MI355RT_E_ARG, "null argument");
+      if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+      int device = 0, cus = 256;
+      HIP_TRY(hipGetDevice(&device));
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+      HIP_TRY(launch_image(rgb_dev, (unsigned long long) width * (unsigned long long) height, normalized, minmax_scratch, argb_dev, cus,
+                           (hipStream_t) hip_stream));
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_image_argb8(const float *rgb, int32_t width, int32_t height, int normalized, uint32_t *argb_out, int32_t device)
 {
-   if (!rgb || !argb_out) return fail(MI355RT_E_ARG, "null argument");
-   if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
-   int n_dev = 0;
-   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
-   if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(MI355RT_E_DEVICE, "hipGetDevice failed");
-   if (device >= n_dev) return fail(MI355RT_E_ARG, "device ordinal out of range");
-   DeviceScope scope(device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   const size_t n = (size_t) width * (size_t) height;
-   float *d_rgb = nullptr;
-   uint32_t *d_out = nullptr;   // n pixels + 2 words of min / max
-   hipError_t e = hipMalloc((void **) &d_rgb, n * 3 * sizeof(float));
-   if (e == hipSuccess) e = hipMalloc((void **) &d_out, (n + 2) * sizeof(uint32_t));
-   if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, n * 3 * sizeof(float), hipMemcpyHostToDevice);
-   int rc = MI355RT_OK;
-   if (e == hipSuccess) rc = mi355rt_image_argb8_device(d_rgb, width, height, normalized, d_out, d_out + n, nullptr);
-   if (e == hipSuccess && rc == MI355RT_OK) e = hipMemcpy(argb_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
-   if (d_rgb) (void) hipFree(d_rgb);
-   if (d_out) (void) hipFree(d_out);
-   if (e != hipSuccess) return hip_fail(e, "mi355rt_image_argb8");
-   return rc;
+   return guarded([&]() -> int {
+      if (!rgb || !argb_out) return fail(MI355RT_E_ARG, "null argument");
+      if (width < 1 || height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+      int n_dev = 0;
+      if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available (libmi355rt has no CPU path)");
+      if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(MI355RT_E_DEVICE, "hipGetDevice failed");
+      if (device >= n_dev) return fail(MI355RT_E_ARG, "device ordinal out of range");
+      DeviceScope scope(device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      const size_t n = (size_t) width * (size_t) height;
+      float *d_rgb = nullptr;
+      uint32_t *d_out = nullptr;   // n pixels + 2 words of min / max
+      hipError_t e = hipMalloc((void **) &d_rgb, n * 3 * sizeof(float));
+      if (e == hipSuccess) e = hipMalloc((void **) &d_out, (n + 2) * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMemcpy(d_rgb, rgb, n * 3 * sizeof(float), hipMemcpyHostToDevice);
+      int rc = MI355RT_OK;
+      if (e == hipSuccess) rc = mi355rt_image_argb8_device(d_rgb, width, height, normalized, d_out, d_out + n, nullptr);
+      if (e == hipSuccess && rc == MI355RT_OK) e = hipMemcpy(argb_out, d_out, n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      if (d_rgb) (void) hipFree(d_rgb);
+      if (d_out) (void) hipFree(d_out);
+      if (e != hipSuccess) return hip_fail(e, "mi355rt_image_argb8");
+      return rc;
+   });
 }
 
 int mi355rt_kernel_profile(mi355rt_scene *scene, mi355rt_kernel_times *out, int reset)
 {
-   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   if (int rc = resolve_times(scene)) return rc;
-   std::memset(out, 0, sizeof(*out));
-   for (int k = 0; k < MI355RT_N_KERNELS; k++) {
-      out->ms[k] = scene->kernel_ms[k];
-      out->launches[k] = scene->kernel_launches[k];
-   }
-   if (scene->stats_valid) {
-      const int kinds[3] = { MI355RT_K_WALK_PRIMARY, MI355RT_K_WALK_SECONDARY, MI355RT_K_WALK_SHADOW };
-      for (int q = 0; q < 3; q++) {   // trace_kernels.hip: ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22
-         out->rays[kinds[q]] = scene->diag[16 + q];
-         out->box_tests[kinds[q]] = scene->diag[19 + q];
-         out->tri_tests[kinds[q]] = scene->diag[22 + q];
-      }
-   }
-   if (reset) {
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      if (int rc = resolve_times(scene)) return rc;
+      std::memset(out, 0, sizeof(*out));
       for (int k = 0; k < MI355RT_N_KERNELS; k++) {
-         scene->kernel_ms[k] = 0.0;
-         scene->kernel_launches[k] = 0;
+         out->ms[k] = scene->kernel_ms[k];
+         out->launches[k] = scene->kernel_launches[k];
       }
-   }
-   return MI355RT_OK;
+      if (scene->stats_valid) {
+         const int kinds[3] = { MI355RT_K_WALK_PRIMARY, MI355RT_K_WALK_SECONDARY, MI355RT_K_WALK_SHADOW };
+         for (int q = 0; q < 3; q++) {   // trace_kernels.hip: ST_KIND_RAYS = 16, ST_KIND_BOX = 19, ST_KIND_TRI = 22
+            out->rays[kinds[q]] = scene->diag[16 + q];
+            out->box_tests[kinds[q]] = scene->diag[19 + q];
+            out->tri_tests[kinds[q]] = scene->diag[22 + q];
+         }
+      }
+      if (reset) {
+         for (int k = 0; k < MI355RT_N_KERNELS; k++) {
+            scene->kernel_ms[k] = 0.0;
+            scene->kernel_launches[k] = 0;
+         }
+      }
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[64])
 {
-   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
-   if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
-   static_assert(N_STATS == 64, "mi355rt_debug_counters hands out N_STATS values");
-   for (int q = 0; q < N_STATS; q++) out[q] = scene->diag[q];
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
+      static_assert(N_STATS == 64, "mi355rt_debug_counters hands out N_STATS values");
+      for (int q = 0; q < N_STATS; q++) out[q] = scene->diag[q];
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_debug_scene_digest(mi355rt_scene *scene, uint64_t out[4])
 {
-   if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-   const void *src[3] = { scene->d_nodes, scene->d_tris, scene->d_fnrm };
-   const size_t bytes[3] = { scene->n_node_recs * sizeof(DevNodeRec), scene->n_tri_floats * sizeof(float), scene->n_fnrm_floats * sizeof(float) };
-   for (int k = 0; k < 3; k++) {
-      std::vector<unsigned char> host(bytes[k]);
-      if (bytes[k]) HIP_TRY(hipMemcpy(host.data(), src[k], bytes[k], hipMemcpyDeviceToHost));
-      uint64_t h = 1469598103934665603ull;   // FNV-1a
-      for (unsigned char c : host) h = (h ^ c) * 1099511628211ull;
-      out[k] = h;
-   }
-   out[3] = scene->any_gpu_build ? 1u : 0u;
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      const void *src[3] = { scene->d_nodes, scene->d_tris, scene->d_fnrm };
+      const size_t bytes[3] = { scene->n_node_recs * sizeof(DevNodeRec), scene->n_tri_floats * sizeof(float), scene->n_fnrm_floats * sizeof(float) };
+      for (int k = 0; k < 3; k++) {
+         std::vector<unsigned char> host(bytes[k]);
+         if (bytes[k]) HIP_TRY(hipMemcpy(host.data(), src[k], bytes[k], hipMemcpyDeviceToHost));
+         uint64_t h = 1469598103934665603ull;   // FNV-1a
+         for (unsigned char c : host) h = (h ^ c) * 1099511628211ull;
+         out[k] = h;
+      }
+      out[3] = scene->any_gpu_build ? 1u : 0u;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, uint64_t n, const float *origins,
                        const float *directions, int32_t *hit_id, int32_t *hit_obj, float *hit_w, float *hit_point, float *hit_normal)
 {
-   if (!scene || !settings) return fail(MI355RT_E_ARG, "null argument");
-   if (n == 0) return MI355RT_OK;
-   if (!origins || !directions) return fail(MI355RT_E_ARG, "null ray arrays");
-   if (n > ((uint64_t) 1 << 30)) return fail(MI355RT_E_LIMIT, "more than 2^30 rays in one call");
-   DeviceScope scope(scene->device);
-   if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+   return guarded([&]() -> int {
+      if (!scene || !settings) return fail(MI355RT_E_ARG, "null argument");
+      if (n == 0) return MI355RT_OK;
+      if (!origins || !directions) return fail(MI355RT_E_ARG, "null ray arrays");
+      if (n > ((uint64_t) 1 << 30)) return fail(MI355RT_E_LIMIT, "more than 2^30 rays in one call");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
 
-   struct Buffers {
-      void *p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-      ~Buffers()
-      {
-         for (void *q : p)
-            if (q) (void) hipFree(q);
-      }
-   } buf;
-   // 0 origins, 1 dirs, 2 rays, 3 hits, 4 hit_obj, 5 out_id, 6 out_obj, 7 out_w, 8 out_point, 9 out_normal
-   const size_t sizes[10] = { n * 12, n * 12, n * 32, n * 32, n * 4, n * 4, n * 4, n * 4, n * 12, n * 12 };
-   for (int i = 0; i < 10; i++) HIP_TRY(hipMalloc(&buf.p[i], sizes[i]));
-   HIP_TRY(hipMemcpy(buf.p[0], origins, sizes[0], hipMemcpyHostToDevice));
-   HIP_TRY(hipMemcpy(buf.p[1], directions, sizes[1], hipMemcpyHostToDevice));
-   TraceBatchArgs a;
-   std::memset(&a, 0, sizeof(a));
-   a.sc.objs = scene->d_objs;
-   a.sc.nodes = scene->d_nodes;
-   a.sc.tris = scene->d_tris;
-   a.sc.fnrm = scene->d_fnrm;
-   a.sc.n_objs = (int32_t) scene->objects.size();
-   a.sc.epsilon = settings->epsilon;
-   a.sc.near_plane = settings->near_plane;
-   a.sc.far_plane = settings->far_plane;
-   a.sc.scene_abs_max = scene->abs_max;
-   a.sc.max_normal_len = scene->max_normal_len;
-   a.sc.ext = scene->d_ext;
-   a.sc.n_analytic = scene->n_analytic;
-   a.sc.boxes_finite = scene->boxes_finite ? 1 : 0;
-   a.n = (uint32_t) n;
-   a.band_cap = (uint32_t) ((n + N_BANDS - 1) / N_BANDS);
-   a.origins = (const float *) buf.p[0];
-   a.dirs = (const float *) buf.p[1];
-   a.rays = (float *) buf.p[2];
-   a.hits = (float *) buf.p[3];
-   a.hit_obj = (int32_t *) buf.p[4];
-   a.counters = scene->d_counters;
-   a.out_id = (int32_t *) buf.p[5];
-   a.out_obj = (int32_t *) buf.p[6];
-   a.out_w = (float *) buf.p[7];
-   a.out_point = (float *) buf.p[8];
-   a.out_normal = (float *) buf.p[9];
-   HIP_TRY(hipMemsetAsync(scene->d_counters, 0, CNT_WORDS * sizeof(uint32_t), nullptr));
-   HIP_TRY(launch_batch_pack(a, nullptr));
-   HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, a.band_cap, n, scene->n_cus, 0, 0, nullptr));
-   HIP_TRY(launch_analytic_closest(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, a.band_cap, n, scene->n_cus, 0, nullptr));
-   HIP_TRY(launch_batch_unpack(a, nullptr));
-   HIP_TRY(hipStreamSynchronize(nullptr));
-   if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[5], sizes[5], hipMemcpyDeviceToHost));
-   if (hit_obj) HIP_TRY(hipMemcpy(hit_obj, buf.p[6], sizes[6], hipMemcpyDeviceToHost));
-   if (hit_w) HIP_TRY(hipMemcpy(hit_w, buf.p[7], sizes[7], hipMemcpyDeviceToHost));
-   if (hit_point) HIP_TRY(hipMemcpy(hit_point, buf.p[8], sizes[8], hipMemcpyDeviceToHost));
-   if (hit_normal) HIP_TRY(hipMemcpy(hit_normal, buf.p[9], sizes[9], hipMemcpyDeviceToHost));
-   return MI355RT_OK;
+      struct Buffers {
+         void *p[10] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+         ~Buffers()
+         {
+            for (void *q : p)
+               if (q) (void) hipFree(q);
+         }
+      } buf;
+      // 0 origins, 1 dirs, 2 rays, 3 hits, 4 hit_obj, 5 out_id, 6 out_obj, 7 out_w, 8 out_point, 9 out_normal
+      const size_t sizes[10] = { n * 12, n * 12, n * 32, n * 32, n * 4, n * 4, n * 4, n * 4, n * 12, n * 12 };
+      for (int i = 0; i < 10; i++) HIP_TRY(hipMalloc(&buf.p[i], sizes[i]));
+      HIP_TRY(hipMemcpy(buf.p[0], origins, sizes[0], hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(buf.p[1], directions, sizes[1], hipMemcpyHostToDevice));
+      TraceBatchArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.sc.objs = scene->d_objs;
+      a.sc.nodes = scene->d_nodes;
+      a.sc.tris = scene->d_tris;
+      a.sc.fnrm = scene->d_fnrm;
+      a.sc.n_objs = (int32_t) scene->objects.size();
+      a.sc.epsilon = settings->epsilon;
+      a.sc.near_plane = settings->near_plane;
+      a.sc.far_plane = settings->far_plane;
+      a.sc.scene_abs_max = scene->abs_max;
+      a.sc.max_normal_len = scene->max_normal_len;
+      a.sc.ext = scene->d_ext;
+      a.sc.n_analytic = scene->n_analytic;
+      a.sc.boxes_finite = scene->boxes_finite ? 1 : 0;
+      a.n = (uint32_t) n;
+      a.band_cap = (uint32_t) ((n + N_BANDS - 1) / N_BANDS);
+      a.origins = (const float *) buf.p[0];
+      a.dirs = (const float *) buf.p[1];
+      a.rays = (float *) buf.p[2];
+      a.hits = (float *) buf.p[3];
+      a.hit_obj = (int32_t *) buf.p[4];
+      a.counters = scene->d_counters;
+      a.out_id = (int32_t *) buf.p[5];
+      a.out_obj = (int32_t *) buf.p[6];
+      a.out_w = (float *) buf.p[7];
+      a.out_point = (float *) buf.p[8];
+      a.out_normal = (float *) buf.p[9];
+      HIP_TRY(hipMemsetAsync(scene->d_counters, 0, CNT_WORDS * sizeof(uint32_t), nullptr));
+      HIP_TRY(launch_batch_pack(a, nullptr));
+      HIP_TRY(launch_trace(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, CNT_CURSOR0, a.band_cap, n, scene->n_cus, 0, 0, nullptr));
+      HIP_TRY(launch_analytic_closest(a.sc, a.rays, a.hits, a.hit_obj, a.counters, CNT_Q0, a.band_cap, n, scene->n_cus, 0, nullptr));
+      HIP_TRY(launch_batch_unpack(a, nullptr));
+      HIP_TRY(hipStreamSynchronize(nullptr));
+      if (hit_id) HIP_TRY(hipMemcpy(hit_id, buf.p[5], sizes[5], hipMemcpyDeviceToHost));
+      if (hit_obj) HIP_TRY(hipMemcpy(hit_obj, buf.p[6], sizes[6], hipMemcpyDeviceToHost));
+      if (hit_w) HIP_TRY(hipMemcpy(hit_w, buf.p[7], sizes[7], hipMemcpyDeviceToHost));
+      if (hit_point) HIP_TRY(hipMemcpy(hit_point, buf.p[8], sizes[8], hipMemcpyDeviceToHost));
+      if (hit_normal) HIP_TRY(hipMemcpy(hit_normal, buf.p[9], sizes[9], hipMemcpyDeviceToHost));
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_div, float *out_sqrt, float *out_rnorm, float *out_pow)
 {
-   if (!a || !b || !out_div || !out_sqrt || !out_rnorm || !out_pow) return fail(MI355RT_E_ARG, "null argument");
-   if (n == 0) return MI355RT_OK;
-   int n_dev = 0;
-   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available");
-   float *d[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-   int rc = MI355RT_OK;
-   for (int i = 0; i < 6 && rc == MI355RT_OK; i++) {
-      hipError_t e = hipMalloc((void **) &d[i], n * sizeof(float));
-      if (e != hipSuccess) rc = hip_fail(e, "hipMalloc");
-   }
-   if (rc == MI355RT_OK) {
-      hipError_t e = hipMemcpy(d[0], a, n * sizeof(float), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(d[1], b, n * sizeof(float), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = launch_arith_probe(n, d[0], d[1], d[2], d[3], d[4], d[5], nullptr);
-      if (e == hipSuccess) e = hipDeviceSynchronize();
-      if (e == hipSuccess) e = hipMemcpy(out_div, d[2], n * sizeof(float), hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(out_sqrt, d[3], n * sizeof(float), hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(out_rnorm, d[4], n * sizeof(float), hipMemcpyDeviceToHost);
-      if (e == hipSuccess) e = hipMemcpy(out_pow, d[5], n * sizeof(float), hipMemcpyDeviceToHost);
-      if (e != hipSuccess) rc = hip_fail(e, "arith probe");
-   }
-   for (float *q : d)
-      if (q) (void) hipFree(q);
-   return rc;
+   return guarded([&]() -> int {
+      if (!a || !b || !out_div || !out_sqrt || !out_rnorm || !out_pow) return fail(MI355RT_E_ARG, "null argument");
+      if (n == 0) return MI355RT_OK;
+      int n_dev = 0;
+      if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(MI355RT_E_DEVICE, "no HIP device available");
+      float *d[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+      int rc = MI355RT_OK;
+      for (int i = 0; i < 6 && rc == MI355RT_OK; i++) {
+         hipError_t e = hipMalloc((void **) &d[i], n * sizeof(float));
+         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc");
+      }
+      if (rc == MI355RT_OK) {
+         hipError_t e = hipMemcpy(d[0], a, n * sizeof(float), hipMemcpyHostToDevice);
+         if (e == hipSuccess) e = hipMemcpy(d[1], b, n * sizeof(float), hipMemcpyHostToDevice);
+         if (e == hipSuccess) e = launch_arith_probe(n, d[0], d[1], d[2], d[3], d[4], d[5], nullptr);
+         if (e == hipSuccess) e = hipDeviceSynchronize();
+         if (e == hipSuccess) e = hipMemcpy(out_div, d[2], n * sizeof(float), hipMemcpyDeviceToHost);
+         if (e == hipSuccess) e = hipMemcpy(out_sqrt, d[3], n * sizeof(float), hipMemcpyDeviceToHost);
+         if (e == hipSuccess) e = hipMemcpy(out_rnorm, d[4], n * sizeof(float), hipMemcpyDeviceToHost);
+         if (e == hipSuccess) e = hipMemcpy(out_pow, d[5], n * sizeof(float), hipMemcpyDeviceToHost);
+         if (e != hipSuccess) rc = hip_fail(e, "arith probe");
+      }
+      for (float *q : d)
+         if (q) (void) hipFree(q);
+      return rc;
+   });
 }
 
 int mi355rt_ply_load(const char *path, uint32_t *n_vertices, uint32_t *n_faces, float **vertices, float **normals, int32_t **indices,
                      int32_t *has_normals)
 {
-   if (!path || !n_vertices || !n_faces || !vertices || !normals || !indices || !has_normals) return fail(MI355RT_E_ARG, "null argument");
-   PlyMesh m;
-   const std::string err = read_ply(path, m);
-   if (!err.empty()) return fail(MI355RT_E_IO, std::string(path) + ": " + err);
-   float *v = (float *) std::malloc(sizeof(float) * (m.vertices.size() ? m.vertices.size() : 1));
-   float *nr = (float *) std::malloc(sizeof(float) * (m.normals.size() ? m.normals.size() : 1));
-   int32_t *ix = (int32_t *) std::malloc(sizeof(int32_t) * (m.indices.size() ? m.indices.size() : 1));
-   if (!v || !nr || !ix) {
-      std::free(v);
-      std::free(nr);
-      std::free(ix);
-      return fail(MI355RT_E_MEMORY, "out of host memory");
-   }
-   if (!m.vertices.empty()) std::memcpy(v, m.vertices.data(), sizeof(float) * m.vertices.size());
-   if (!m.normals.empty()) std::memcpy(nr, m.normals.data(), sizeof(float) * m.normals.size());
-   if (!m.indices.empty()) std::memcpy(ix, m.indices.data(), sizeof(int32_t) * m.indices.size());
-   *n_vertices = (uint32_t) (m.vertices.size() / 3);
-   *n_faces = (uint32_t) (m.indices.size() / 3);
-   *vertices = v;
-   *normals = nr;
-   *indices = ix;
-   *has_normals = m.has_normals ? 1 : 0;
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if (!path || !n_vertices || !n_faces || !vertices || !normals || !indices || !has_normals) return fail(MI355RT_E_ARG, "null argument");
+      PlyMesh m;
+      const std::string err = read_ply(path, m);
+      if (!err.empty()) return fail(MI355RT_E_IO, std::string(path) + ": " + err);
+      float *v = (float *) std::malloc(sizeof(float) * (m.vertices.size() ? m.vertices.size() : 1));
+      float *nr = (float *) std::malloc(sizeof(float) * (m.normals.size() ? m.normals.size() : 1));
+      int32_t *ix = (int32_t *) std::malloc(sizeof(int32_t) * (m.indices.size() ? m.indices.size() : 1));
+      if (!v || !nr || !ix) {
+         std::free(v);
+         std::free(nr);
+         std::free(ix);
+         return fail(MI355RT_E_MEMORY, "out of host memory");
+      }
+      if (!m.vertices.empty()) std::memcpy(v, m.vertices.data(), sizeof(float) * m.vertices.size());
+      if (!m.normals.empty()) std::memcpy(nr, m.normals.data(), sizeof(float) * m.normals.size());
+      if (!m.indices.empty()) std::memcpy(ix, m.indices.data(), sizeof(int32_t) * m.indices.size());
+      *n_vertices = (uint32_t) (m.vertices.size() / 3);
+      *n_faces = (uint32_t) (m.indices.size() / 3);
+      *vertices = v;
+      *normals = nr;
+      *indices = ix;
+      *has_normals = m.has_normals ? 1 : 0;
+      return MI355RT_OK;
+   });
 }
 
 int mi355rt_compute_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, float *normals_out)
 {
-   if ((n_vertices && !vertices) || (n_faces && !indices) || !normals_out) return fail(MI355RT_E_ARG, "null argument");
-   for (size_t i = 0; i < 3 * (size_t) n_faces; i++) {
-      if (indices[i] < 0 || (uint32_t) indices[i] >= n_vertices) return fail(MI355RT_E_ARG, "face index out of range");
-   }
-   synthesise_normals(vertices, n_vertices, indices, n_faces, normals_out);
-   return MI355RT_OK;
+   return guarded([&]() -> int {
+      if ((n_vertices && !vertices) || (n_faces && !indices) || !normals_out) return fail(MI355RT_E_ARG, "null argument");
+      for (size_t i = 0; i < 3 * (size_t) n_faces; i++) {
+         if (indices[i] < 0 || (uint32_t) indices[i] >= n_vertices) return fail(MI355RT_E_ARG, "face index out of range");
+      }
+      synthesise_normals(vertices, n_vertices, indices, n_faces, normals_out);
+      return MI355RT_OK;
+   });
 }
 
 void mi355rt_free(void *p) { std::free(p); }

@@ -129,6 +129,34 @@ std::string read_ply(const char *path, PlyMesh &out)
    if (sx < 0 || sy < 0 || sz < 0) return "header declares no x/y/z vertex properties";
    const bool has_n = snx >= 0 && sny >= 0 && snz >= 0;
 
+   // The header's counts size the arrays, so they are checked against what the file can hold BEFORE anything is
+   // allocated (a 100-byte file declaring two billion vertices must be an error, not a 48 GB request).  Binary:
+   // the exact block sizes.  ASCII: every vertex line and every face line is at least one byte long; a file with
+   // fewer face lines than declared keeps zero rows for the rest, as the reference's int[numFaces][3] does.
+   const char *body = nullptr, *body_end = data.data() + data.size();
+   if (ascii) {
+      body = cur.p;
+   } else {
+      // the reference re-opens the file and skips '\n'-terminated lines up to the one that starts with "end_header"
+      const char *q = data.data();
+      for (;;) {
+         const char *nl = (const char *) std::memchr(q, '\n', (size_t) (body_end - q));
+         if (!nl) return "binary file has no end_header line";
+         const bool last = has_prefix(q, nl, "end_header");
+         q = nl + 1;
+         if (last) break;
+      }
+      body = q;
+   }
+   const size_t body_bytes = (size_t) (body_end - body);
+   if (ascii) {
+      if ((size_t) n_vertices > body_bytes) return "'element vertex' declares more vertices than the file has bytes left";
+      if ((size_t) n_faces > body_bytes) return "'element face' declares more faces than the file has bytes left";
+   } else {
+      if ((size_t) n_vertices * (size_t) slot * 4 > body_bytes) return "file ends inside the vertex block";
+      if ((size_t) n_faces * 13 > body_bytes - (size_t) n_vertices * (size_t) slot * 4) return "file ends inside the face block";
+   }
+
    out = PlyMesh();
    out.has_normals = has_n;
    out.vertices.assign(3 * (size_t) n_vertices, 0.0f);
@@ -162,16 +190,8 @@ std::string read_ply(const char *path, PlyMesh &out)
       return std::string();
    }
 
-   // binary: the reference re-opens the file and skips '\n'-terminated lines up to the one that
-   // starts with "end_header"
-   const char *q = data.data(), *qe = data.data() + data.size();
-   for (;;) {
-      const char *nl = (const char *) std::memchr(q, '\n', (size_t) (qe - q));
-      if (!nl) return "binary file has no end_header line";
-      const bool last = has_prefix(q, nl, "end_header");
-      q = nl + 1;
-      if (last) break;
-   }
+   // binary body (sizes checked above)
+   const char *q = body, *qe = body_end;
    const size_t vbytes = (size_t) n_vertices * (size_t) slot * 4;
    const size_t fbytes = (size_t) n_faces * 13;
    if ((size_t) (qe - q) < vbytes) return "file ends inside the vertex block";

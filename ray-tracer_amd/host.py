@@ -322,13 +322,12 @@ class Scene:
 
         descs = (_abi.ObjectDesc * max(len(self.objects), 1))()
         keep = []
-        use_kd = True
         for k, obj in enumerate(self.objects):   # TriangleMesh, Sphere or Plane, in Scene.objects order
             obj._fill(descs[k], keep)
             descs[k].mesh.material = obj.colorInfo._abi_material()
             descs[k].ext = obj.colorInfo._abi_material_ext()
-            use_kd = use_kd and obj.computeKDTree
-        opts = _abi.BuildOpts(RTStatics.MAX_DEPTH, RTStatics.MAX_CHILDREN, 1 if use_kd else 0, int(device))
+            descs[k].mesh.compute_kdtree = 1 if obj.computeKDTree else -1   # per mesh, as TriangleMesh.java:89 passes it on
+        opts = _abi.BuildOpts(RTStatics.MAX_DEPTH, RTStatics.MAX_CHILDREN, 1, int(device))
         _abi.check(self._lib.mi355rt_scene_create_objects(descs, len(self.objects), C.byref(opts), C.byref(self._handle)))
         if any(isinstance(m.colorInfo, BRDFMaterial) for m in self.objects):
             if BRDFMaterial.tables is None:
@@ -376,7 +375,7 @@ class Camera:
     """Camera(scene, multiSamples, brdfSamples, nearPlane, screenWidth, screenHeight).
 
     createImage() is the drop-in seam (Camera.java:119): here it blocks until the frame is done and
-    fills `pixels` (float32 [W][H][3], as Camera.pixels[x][y]), `hit_id` and `hit_w` ([W][H])."""
+    fills `pixels` (float32 [W][H][3], as Camera.pixels[x][y]), `hit_id`, `hit_obj` and `hit_w` ([W][H])."""
 
     def __init__(self, scene, multiSamples, brdfSamples, nearPlane, screenWidth, screenHeight, rng_seed=0):
         self.scene = scene
@@ -404,6 +403,7 @@ class Camera:
         self.viewportHeight = float(self._cam.viewport_h)
         self.pixels = None
         self.hit_id = None
+        self.hit_obj = None
         self.hit_w = None
         self.lightingModel.setCamera(self)
 
@@ -443,12 +443,13 @@ class Camera:
             W, H = self.screenWidth, self.screenHeight
             n = W * H
             ptr = C.c_void_p()
-            _abi.check(self._lib.mi355rt_host_alloc(n * 20, C.byref(ptr)))
+            _abi.check(self._lib.mi355rt_host_alloc(n * 24, C.byref(ptr)))
             self._pinned_ptr = ptr
-            base = (C.c_uint8 * (n * 20)).from_address(ptr.value)
+            base = (C.c_uint8 * (n * 24)).from_address(ptr.value)
             self._pinned = (np.frombuffer(base, dtype=np.float32, count=n * 3).reshape(H, W, 3),
                             np.frombuffer(base, dtype=np.int32, count=n, offset=n * 12).reshape(H, W),
-                            np.frombuffer(base, dtype=np.float32, count=n, offset=n * 16).reshape(H, W))
+                            np.frombuffer(base, dtype=np.int32, count=n, offset=n * 16).reshape(H, W),
+                            np.frombuffer(base, dtype=np.float32, count=n, offset=n * 20).reshape(H, W))
 
     def __del__(self):
         try:
@@ -460,16 +461,18 @@ class Camera:
     def createImage(self):
         W, H = self.screenWidth, self.screenHeight
         if self._pinned:
-            rgb, hid, hw = self._pinned
+            rgb, hid, hobj, hw = self._pinned
         else:
             rgb = np.empty((H, W, 3), dtype=np.float32)
             hid = np.empty((H, W), dtype=np.int32)
+            hobj = np.empty((H, W), dtype=np.int32)
             hw = np.empty((H, W), dtype=np.float32)
         st = self.settings()
-        _abi.check(self._lib.mi355rt_render(self.scene._handle, C.byref(self._cam), C.byref(st), _fp(rgb), _ip(hid), _fp(hw)))
+        _abi.check(self._lib.mi355rt_render(self.scene._handle, C.byref(self._cam), C.byref(st), _fp(rgb), _ip(hid), _ip(hobj), _fp(hw)))
         self._rgb_rows = rgb
         self.pixels = rgb.transpose(1, 0, 2)   # [x][y][c] like Camera.pixels
         self.hit_id = hid.T
+        self.hit_obj = hobj.T                  # index into Scene.objects (IntersectionInformation.intersectionObject), -1 = miss
         self.hit_w = hw.T
         for listener in self.listeners:   # ActionEvent id 1, "finished" (Camera.java:170-172)
             listener(self, 1, "finished")

@@ -76,6 +76,7 @@ static int write_frame(const Camera &camera, int W, int H, const char *path)
    std::fwrite(camera.rowMajorPixels().data(), sizeof(float), (size_t) 3 * W * H, f);
    std::fwrite(camera.hitId.data(), sizeof(int32_t), (size_t) W * H, f);
    std::fwrite(camera.hitW.data(), sizeof(float), (size_t) W * H, f);
+   std::fwrite(camera.hitObj.data(), sizeof(int32_t), (size_t) W * H, f);
    std::fclose(f);
    std::printf("RENDER_OK %dx%d pixel(0,0)=%g\n", W, H, camera.getPixel(0, 0)[0]);
    return 0;

@@ -56,7 +56,7 @@ def random_case(rt, seed):
         o = dict(pair.oscene.render(ocam, ost, n_threads=8))
         g = np.nan_to_num(cam._rgb_rows, nan=-1.0)   # a NaN-scrubbed pixel must be one on both sides
         o["rgb"] = np.nan_to_num(o["rgb"], nan=-1.0)
-        ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o)
+        ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
         ok = ids_equal and w_equal and max_rel <= 1e-3
         desc = "seed %d scale %g objs %d light %d fuse %r %dx%dx%d hits %.2f: %s (ids %s w %s rel %.2e diff %d)" % (
             seed, scale, len(objs), kind, fuse, W, H, ms, float((o["hit_id"] >= 0).mean()), "ok" if ok else "MISMATCH", ids_equal,
@@ -114,7 +114,7 @@ def random_analytic_case(rt, seed):
     g = np.nan_to_num(cam._rgb_rows, nan=-1.0)
     o["rgb"] = np.nan_to_num(o["rgb"], nan=-1.0)
     # hit ids of analytic objects are -1 on both sides (no faces): the object index is compared through w and radiance
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
     ok = ids_equal and w_equal and max_rel <= 1e-3
     desc = "analytic seed %d objs %d %dx%dx%d hits(w>0) %.2f: %s (ids %s w %s rel %.2e diff %d)" % (
         seed, len(objs), W, H, ms, float((o["hit_w"] > 0).mean()), "ok" if ok else "MISMATCH", ids_equal, w_equal, max_rel, n_diff)

@@ -24,9 +24,10 @@ def _both_sides(entry, use_kdtree):
         return entry, oracle.sphere(entry.origin, entry.radius, to_orc_material(entry.colorInfo), to_orc_ext(entry.colorInfo))
     if isinstance(entry, rt.Plane):
         return entry, oracle.plane(entry.corners.tolist(), to_orc_material(entry.colorInfo), to_orc_ext(entry.colorInfo))
-    v, i, n, ci = entry
-    return (rt.TriangleMesh((v, i) if n is None else (v, i, n), ci, use_kdtree),
-            (v, i, n, to_orc_material(ci), to_orc_ext(ci)))
+    v, i, n, ci = entry[:4]
+    kd = bool(entry[4]) if len(entry) > 4 else use_kdtree   # this mesh's own computeKDTree (TriangleMesh.java:23,89)
+    return (rt.TriangleMesh((v, i) if n is None else (v, i, n), ci, kd),
+            (v, i, n, to_orc_material(ci), to_orc_ext(ci), kd))
 
 
 class Pair:
@@ -34,7 +35,7 @@ class Pair:
 
     def __init__(self, meshes, orientation=(0, 0, 0), fov=15.0, phong=True, light=None, brdf_tables=None,
                  use_kdtree=True):
-        # meshes: list of (vertices, indices, normals-or-None, ColorInformation) and rt.Sphere / rt.Plane objects
+        # meshes: list of (vertices, indices, normals-or-None, ColorInformation[, computeKDTree]) and rt.Sphere / rt.Plane objects
         light = light or LIGHT
         self.light = rt.Light(light["origin"], light["emission"], light["ambient"])
         if brdf_tables is not None:
@@ -81,13 +82,17 @@ def synthetic_brdf_tables(n_dirs=205, n_materials=8, seed=7):
     return ang, w
 
 
-def compare_frames(g_rgb, g_id, g_w, o, rtol=1e-3, atol=1e-6):
-    """ids and w bit-exact; radiance within 1e-3 relative (north_star), NaN-scrubbed pixels equal."""
-    ids_equal = np.array_equal(g_id, o["hit_id"])
+def compare_frames(g_rgb, g_id, g_w, o, rtol=1e-3, atol=1e-6, g_obj=None):
+    """ids, hit objects and w bit-exact; radiance within 1e-3 relative (north_star), NaN-scrubbed pixels equal.
+    g_obj: the frame's hit-object indices (a face index alone does not tell two objects' faces apart)."""
+    same = g_id == o["hit_id"]
+    if g_obj is not None:
+        same = same & (g_obj == o["hit_obj"])
+    ids_equal = bool(same.all())
     w_equal = np.array_equal(g_w.view(np.uint32), o["hit_w"].view(np.uint32))
     denom = np.maximum(np.abs(o["rgb"]), atol / rtol)
     rel = np.abs(g_rgb - o["rgb"]) / denom
-    return ids_equal, w_equal, float(rel.max()), int((g_id != o["hit_id"]).sum())
+    return ids_equal, w_equal, float(rel.max()), int((~same).sum())
 
 
 # ---------------------------------------------------------------- the reference's analytic scenes (shared with tests/golden/make_golden.py)

@@ -24,7 +24,7 @@ class Material(C.Structure):
 
 class MeshDesc(C.Structure):
     _fields_ = [("vertices", fp), ("normals", fp), ("indices", ip), ("n_vertices", C.c_uint32),
-                ("n_faces", C.c_uint32), ("material", Material)]
+                ("n_faces", C.c_uint32), ("material", Material), ("compute_kdtree", C.c_int32)]
 
 
 class MaterialExt(C.Structure):
@@ -214,6 +214,8 @@ class OracleScene:
             descs[k].mesh.material = m
             if len(entry) > 4 and entry[4] is not None:
                 descs[k].ext = entry[4]
+            if len(entry) > 5 and entry[5] is not None:   # this mesh's own computeKDTree (TriangleMesh.java:89)
+                descs[k].mesh.compute_kdtree = 1 if entry[5] else -1
         self.n_vertices = [d.mesh.n_vertices for d in descs[: len(meshes)]]
         opts = BuildOpts(max_depth, max_children, 1 if use_kdtree else 0, -1)
         self.h = C.c_void_p()

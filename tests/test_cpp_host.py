@@ -40,6 +40,7 @@ def test_cpp_mirror_frame_matches_oracle(rt, orc, tmp_path):
     rgb = body[: 3 * W * H].reshape(H, W, 3)
     hid = body[3 * W * H: 4 * W * H].view(np.int32).reshape(H, W)
     hw = body[4 * W * H: 5 * W * H].reshape(H, W)
+    hobj = body[5 * W * H: 6 * W * H].view(np.int32).reshape(H, W)
     ov, oi, on = orc.ply_load(ply)
     osc = orc.OracleScene([(ov, oi, on, orc.material(diffuse=(0.9, 0.9, 0.9)))])
     ocam = osc.camera((0, 0, 0), fov, 0.01, W, H)
@@ -47,7 +48,7 @@ def test_cpp_mirror_frame_matches_oracle(rt, orc, tmp_path):
     assert np.float32(osc.epsilon()) == header[5]
     ost = orc.settings(epsilon=osc.epsilon(), ms=ms, lighting=1, seed=seed)
     o = osc.render(ocam, ost, n_threads=8)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(rgb, hid, hw, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(rgb, hid, hw, o, g_obj=hobj)
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     assert (hid >= 0).mean() > 0.1
     osc.close()
@@ -67,6 +68,7 @@ def test_cpp_mirror_whitted_scene_matches_oracle(orc, tmp_path):
     rgb = body[: 3 * W * H].reshape(H, W, 3)
     hid = body[3 * W * H: 4 * W * H].view(np.int32).reshape(H, W)
     hw = body[4 * W * H: 5 * W * H].reshape(H, W)
+    hobj = body[5 * W * H: 6 * W * H].view(np.int32).reshape(H, W)
     floor = orc.plane([(-50, 0, -100), (-50, -40, 25), (50, -40, 25), (50, 0, -100)], orc.material(4, (0, 0, 0), 20.0),
                       orc.material_ext(0, (1, 1, 0), (1, 0, 0), (10, 10, 10)))
     glass = orc.sphere((0, -12, 0), 5, orc.material(3, (128 / 255.0,) * 3, 100.0), orc.material_ext(1.52))
@@ -77,7 +79,7 @@ def test_cpp_mirror_whitted_scene_matches_oracle(orc, tmp_path):
     assert np.float32(osc.epsilon()) == header[5] == np.float32(1e-3)
     ost = orc.settings(epsilon=osc.epsilon(), ms=ms, lighting=1, seed=seed)
     o = osc.render(ocam, ost, n_threads=8)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(rgb, hid, hw, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(rgb, hid, hw, o, g_obj=hobj)
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     assert set(np.unique(o["hit_obj"])) == {-1, 0, 1, 2}
     osc.close()

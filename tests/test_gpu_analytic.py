@@ -17,7 +17,7 @@ def _check(pair, W, H, ms=1, brdf_samples=1, seed=0, rtol=1e-3, origin=None, min
     np.testing.assert_array_equal(np.array(ocam.rotation[:], dtype=np.float32).reshape(3, 3), cam.rotation)
     cam.createImage()
     o = pair.oscene.render(ocam, ost, n_threads=8, want_stats=True)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, rtol=rtol)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, rtol=rtol, g_obj=cam.hit_obj.T)
     assert ids_equal, "%d pixels differ in hit id" % n_diff
     assert w_equal
     assert max_rel <= rtol, max_rel
@@ -175,6 +175,6 @@ def test_tile_shards_and_passes_with_analytic_objects(rt):
     cam2, ocam, ost = pair.cameras(1920, 1088, ms=9, seed=4)
     cam2.createImage()
     o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=1)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam2._rgb_rows, cam2.hit_id.T, cam2.hit_w.T, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam2._rgb_rows, cam2.hit_id.T, cam2.hit_w.T, o, g_obj=cam2.hit_obj.T)
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     pair.close()

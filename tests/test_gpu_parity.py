@@ -21,7 +21,7 @@ def _check(pair, W, H, ms=1, brdf_samples=1, seed=0, rtol=1e-3):
     np.testing.assert_array_equal(np.array(ocam.rotation[:], dtype=np.float32).reshape(3, 3), cam.rotation)
     cam.createImage()
     o = pair.oscene.render(ocam, ost, n_threads=8)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, rtol=rtol)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, rtol=rtol, g_obj=cam.hit_obj.T)
     assert ids_equal, "%d pixels differ in hit id" % n_diff
     assert w_equal
     assert max_rel <= rtol, max_rel
@@ -82,6 +82,25 @@ def test_no_kdtree(rt):
     pair = _blob_pair(rt, 600, use_kdtree=False)
     _check(pair, 48, 48)
     pair.close()
+
+
+def test_kdtree_flag_is_per_mesh(rt):
+    """computeKDTree belongs to each TriangleMesh (TriangleMesh.java:23,89): a mesh built without the hierarchy next
+    to one built with it.  Both hold every face twice, so equal distances are everywhere, and the two forms break
+    the ties differently (one leaf: the first face; a tree: the later leaf) -- each object must keep its own rule."""
+    from helpers import Pair
+    v, i = rt.meshgen.blob(1500, span=0.15, seed=3)
+    i2 = np.concatenate([i, i[::-1]], axis=0)
+    shift = np.array([0.09, 0.02, -0.03], dtype=np.float32)
+    for flags in ((True, False), (False, True)):
+        pair = Pair([(v, i2, None, rt.ColorInformation((1.0, 0.8, 0.6)), flags[0]),
+                     ((v + shift).astype(np.float32), i2, None, rt.ColorInformation((0.6, 0.8, 1.0)), flags[1])], fov=20.0)
+        info = [pair.scene.object_info(k) for k in range(2)]
+        assert [bool(x["n_nodes"]) for x in info] == list(flags)
+        assert [pair.oscene.object_info(k)["n_leaves"] > 1 for k in range(2)] == list(flags)
+        frac = _check(pair, 128, 96, ms=2, seed=5)
+        assert frac > 0.1
+        pair.close()
 
 
 def test_brdf_material(rt):

@@ -40,7 +40,7 @@ def test_dragon_config_full_size_vs_oracle(rt, orc):
     ost = orc.settings(epsilon=osc.epsilon(), ms=4, lighting=1, seed=2024, light_origin=light.origin,
                        light_emission=light.emission, light_ambient=light.ambient)
     o = osc.render(ocam, ost, n_threads=16)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
     assert ids_equal, "%d pixels differ in hit id" % n_diff
     assert w_equal
     assert max_rel <= 1e-3, max_rel
@@ -89,7 +89,7 @@ def test_multi_pass_frame(rt, orc):
     ost = orc.settings(epsilon=osc.epsilon(), ms=ms, lighting=1, seed=3, light_origin=light.origin,
                        light_emission=light.emission, light_ambient=light.ambient)
     o = osc.render(ocam, ost, n_threads=16)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     osc.close()
     scene.close()
@@ -194,7 +194,7 @@ def test_mirror_bounces_between_two_mirrors(rt, orc):
     cam, ocam, ost = pair.cameras(160, 100, ms=2, seed=17)
     cam.createImage()
     o = pair.oscene.render(ocam, ost, n_threads=8, want_stats=True)
-    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     assert o["stats"]["secondary_rays"] > 1000
     pair.close()
@@ -207,12 +207,12 @@ def test_error_behaviour(rt):
     cam = rt.Camera(scene, 1, 1, rt.RTStatics.NEAR_PLANE, 32, 32)
     st = cam.settings()
     st.multi_samples = 0
-    rc = lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None)
+    rc = lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None, None)
     assert rc == rt._abi.E_ARG and b"multi_samples" in lib.mi355rt_last_error()
     st = cam.settings(tile_rank=2, tile_world=2)
-    assert lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None) == rt._abi.E_ARG
+    assert lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None, None) == rt._abi.E_ARG
     st = cam.settings(tile_size=12)
-    assert lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None) == rt._abi.E_ARG
+    assert lib.mi355rt_render(scene._handle, C.byref(cam._cam), C.byref(st), None, None, None, None) == rt._abi.E_ARG
     # a BRDF material whose row is outside the loaded tables (8 rows)
     from helpers import synthetic_brdf_tables
     v, i = rt.meshgen.blob(500, span=0.2)

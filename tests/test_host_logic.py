@@ -71,6 +71,29 @@ def test_ply_reference_quirks(rt, orc, tmp_path):
     assert e.value.code == rt._abi.E_IO
 
 
+@pytest.mark.parametrize("binary", [False, True])
+def test_ply_counts_beyond_the_file_are_an_error_not_an_allocation(rt, tmp_path, binary):
+    """A short file whose header declares two billion vertices / faces must come back as MI355RT_E_IO (the
+    reference exits with an exception, TriangleMesh.java:90-93) -- never as a 48 GB request or an exception
+    leaving the C ABI (which would terminate the host process)."""
+    fmt = "binary_big_endian" if binary else "ascii"
+    head = ("ply\nformat %s 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+            "element face %d\nproperty list uchar int vertex_indices\nend_header\n")
+    for nv, nf in ((2000000000, 1), (3, 2000000000), (2147483647, 2147483647)):
+        path = str(tmp_path / ("huge_%d_%d.ply" % (nv, nf)))
+        with open(path, "wb") as f:
+            f.write((head % (fmt, nv, nf)).encode())
+            f.write(b"0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n" if not binary else b"\0" * 49)
+        with pytest.raises(rt._abi.Mi355rtError) as e:
+            rt.load_ply(path)
+        assert e.value.code == rt._abi.E_IO
+    # an ASCII file with fewer face lines than declared keeps zero rows, as the reference's int[numFaces][3] does
+    path = str(tmp_path / "short_faces.ply")
+    open(path, "w").write((head % ("ascii", 3, 3)) + "0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    v, i, n = rt.load_ply(path)
+    np.testing.assert_array_equal(i, [[0, 1, 2], [0, 0, 0], [0, 0, 0]])
+
+
 def test_compute_normals_library_vs_oracle(rt, orc):
     v, i = rt.meshgen.blob(2000, span=0.2, seed=8)
     got = rt.compute_normals(v, i)
