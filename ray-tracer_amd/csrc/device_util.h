@@ -125,24 +125,34 @@ __device__ __forceinline__ float prune_limit2(const Ray &r, float w, float scene
    return lim * lim;
 }
 
-// How far a shadow ray has to look (MODE_SHADOW, the reference-exact form).  RTStatics.shadowIntersects accepts an
-// object's closest hit only if w < distance(hit point, light) + EPSILON (RTStatics.java:628-633) -- the distance from
-// the HIT to the light, not from the origin.  The origin is the shaded point P0 moved by N * EPSILON (|N| <= max_n),
-// the direction points from P0 to the light, so a hit at distance t along the ray lies within e = max_n * EPSILON of
-// the segment P0 -> light, and distance(hit, light) <= e + |t - D0| with D0 = |light - P0| <= D + e, D = |light - o|.
-// For t <= D0 the test needs t < (D + 2 e + EPSILON) / 2; for t > D0 it needs D0 < e + EPSILON, excluded below.  So
-// no face farther than W = (D + 2 e + EPSILON) / 2 (taken with 0.1 % on top, and prune_limit2's own margin) can
-// occlude, and boxes beyond it are pruned exactly as boxes beyond a found hit are.  Returns the squared limit,
-// +inf when the bound does not apply (light within a few EPSILON of the surface, non-finite data).
-__device__ __forceinline__ float shadow_reach2(const Ray &r, V3 light, float eps, float max_n, float scene_abs_max)
+// MODE_SHADOW, the reference-exact shadow query.  RTStatics.shadowIntersects takes an object's CLOSEST accepted hit c
+// (distance w_c = |o - P_c| from the ray origin to the interpolated point P_c, which lies in its face, hence in every
+// box around that face -- but not necessarily on the ray: for a face almost parallel to the ray the barycentrics are
+// rounding noise) and calls the object an occluder iff w_c > EPSILON && w_c < |P_c - light| + EPSILON
+// (RTStatics.java:626-633).  Two exact shortcuts follow from the triangle inequality alone, with D = |o - light|:
+//   (1) stop early: |P_c - light| >= D - w_c, so any closest hit with w_c < (D + EPSILON) / 2 passes.  Hence once ANY
+//       accepted face a of the object has w_a safely below D / 2, the closest one has too (w_c <= w_a): the object
+//       occludes, whatever else the walk would find (needs shadowDistance >= EPSILON, so that w_c > EPSILON as well).
+//   (2) skip hopeless boxes: every face in a box has w >= dist(o, box) and |P - light| <= the distance from the light to
+//       the box's farthest corner; when dist(o, box) exceeds that (plus EPSILON and margins) no face in it can pass.
+//       Skipping them can only remove failing candidates, so: no candidate left -> the closest (if any) failed -> no
+//       occluder; the closest remaining candidate fails -> the true closest is it or a skipped one -> no occluder.
+//       Only "the closest remaining candidate PASSES" without (1) having fired is undecided (a skipped face might have
+//       been closer): that ray walks the object again with (1) and (2) off.  With hit points on the ray this needs a
+//       hit inside the margin band around D / 2; it is there for the noise cases above.
+// shadow_safe_w: the distance below which (1) applies, <= 0 when it never does.  m bounds the rounding of every
+// distance involved (coordinates up to the scene's size), as in prune_limit2.
+__device__ __forceinline__ float shadow_safe_w(const Ray &r, V3 light, float scene_abs_max)
 {
-   const float D = distance3(r.o, light);
-   const float e = max_n * eps;
-   if (!(D > 4.0f * (e + eps))) return __builtin_inff();
-#ifndef SHADOW_REACH_FACTOR
-#define SHADOW_REACH_FACTOR 0.5f   // a test build with a smaller factor must fail the exact-shadow parity test
-#endif
-   return prune_limit2(r, (D + 2.0f * e + eps) * SHADOW_REACH_FACTOR * 1.001f, scene_abs_max);
+   const float m = 1e-5f * (scene_abs_max + fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z) + fabsf(light.x) + fabsf(light.y) + fabsf(light.z));
+   const float t = distance3(r.o, light) * 0.5f * 0.999f - 2.0f * m;
+   return t == t ? t : 0.0f;
+}
+// squared distance from the light to the farthest corner of a box
+__device__ __forceinline__ float light_far2(V3 light, float lox, float loy, float loz, float hix, float hiy, float hiz)
+{
+   const float fx = fmaxf(light.x - lox, hix - light.x), fy = fmaxf(light.y - loy, hiy - light.y), fz = fmaxf(light.z - loz, hiz - light.z);
+   return fx * fx + fy * fy + fz * fz;
 }
 
 // Triangle.intersectsTriangle (sceneObjects/Triangle.java:85-133) on one leaf slot.

@@ -26,6 +26,7 @@
 // order-independently on (distance, first-slot-of-leaf).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 
 #include "analytic.h"
@@ -375,6 +376,7 @@ struct WalkArgs {
    float *mat0;
    const uint32_t *shadow;
    float light[3];
+   float light_prune_c;      // MODE_SHADOW: a box is hopeless when dist2(origin, box) > 1.0001 * far2(light, box) + this (device_util.h); NaN = never
    uint32_t *counters;
    int32_t count_index, cursor_index;   // first of N_BANDS counters / cursors
    uint32_t band_cap;                   // slots per band sub-queue
@@ -397,6 +399,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #endif
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
+#endif
+#ifndef DIAG_MAIL
+#define DIAG_MAIL 8
 #endif
 constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip (<= LEAF_PAD_SLOTS + 1)
 
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       unsigned plain : 1;      // finite origin and 1/direction (and finite node boxes): no NaN can arise in the slab test
       unsigned unsaved : 1;    // closest modes, ROLE_IDLE: the finished ray's result is still in registers (see "retire" below)
       unsigned shadow : 1;     // MODE_FUSED: this lane walks (or helps walk) a shadow ray
+      unsigned redo : 1;       // MODE_SHADOW: the object is being walked again without the two shortcuts (device_util.h)
    } st;
    constexpr bool CLOSEST = MODE == MODE_CLOSEST || MODE == MODE_FUSED;   // rays come from the queue; faces wait in `pend`
    constexpr bool FUSED = MODE == MODE_FUSED;
@@ -444,6 +450,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    st.plain = 0;
    st.unsaved = 0;
    st.shadow = 0;
+   st.redo = 0;
+   float safe_w = 0.0f;   // MODE_SHADOW: an accepted face nearer than this ends the walk of its object (shadow_safe_w)
    int cur = STACK_EMPTY;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
@@ -460,6 +468,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    unsigned d_ray_trips = 0, d_ray_trips_max = 0;
    unsigned d_hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
    unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_lane = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
+   int d_mail[DIAG_MAIL];
+   for (int e = 0; e < DIAG_MAIL; e++) d_mail[e] = -1;   // diagnostics: the last faces this lane's ray tested (how many tests are repeats?)
+   unsigned d_mail_pos = 0, d_repeat = 0;
    const unsigned long long t_begin = STATS ? wall_clock64() : 0ull;   // 100 MHz
    unsigned long long t_exhausted = 0ull;
    unsigned d_tail_trips = 0;   // wave trips after the queue ran dry
@@ -533,6 +544,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // ---- (2) an owner whose walk of object k has ended (and whose helpers are all back): fold the
          // object's result, enter the next object or retire the ray
          if (st.role == ROLE_OWNER && cur == STACK_EMPTY && st.pending == 0) {
+            bool redo_k = false;
             if (st.k >= 0 && ob_slot >= 0) {
                if (CLOSEST && !(FUSED && st.shadow)) {
                   if ((ob_w > eps) && (best_obj < 0 || ob_w < best_w)) {   // Camera.java:208
@@ -543,14 +555,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                } else if (MODE == MODE_SHADOW_ANY || FUSED) {
                   occluded = true;
                } else if (ob_w > eps) {   // RTStatics.java:628-633
-                  const float4 *t = tris + 3 * (size_t) ob_slot;
-                  float u, v, dist;
-                  V3 P;
-                  (void) tri_test(t[0], t[1], t[2], r, eps, u, v, P, dist);
-                  if (ob_w < distance3(P, light) + eps) occluded = true;
+                  if (ob_w < safe_w) {
+                     occluded = true;   // shortcut 1 (device_util.h): the closest face is at most this far, and passes
+                  } else {
+                     const float4 *t = tris + 3 * (size_t) ob_slot;
+                     float u, v, dist;
+                     V3 P;
+                     (void) tri_test(t[0], t[1], t[2], r, eps, u, v, P, dist);
+                     if (ob_w < distance3(P, light) + eps) {
+                        // after the full walk (redo) this IS the closest face; otherwise a skipped box might have held a
+                        // closer one that fails the test: walk this object again without the shortcuts
+                        if (st.redo) occluded = true;
+                        else redo_k = true;
+                     }
+                  }
                }
             }
-            int nk = st.k + 1;
+            if (MODE == MODE_SHADOW) st.redo = redo_k ? 1 : 0;
+            int nk = redo_k ? st.k : st.k + 1;
             if (CLOSEST && nk == st.mirror) ++nk;
             const bool done = (nk >= n_objs) || (MODE != MODE_CLOSEST && occluded);
             if (!done) {
@@ -560,8 +582,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                ob_w = 0.0f;
                ob_key = 0;
                sp = bot = 0;
-               lim2 = (CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max)
-                      : (MODE == MODE_SHADOW ? shadow_reach2(r, light, eps, a.sc.max_normal_len, abs_max) : __builtin_inff());
+               lim2 = (CLOSEST && best_obj >= 0) ? prune_limit2(r, best_w, abs_max) : __builtin_inff();
+               if (MODE == MODE_SHADOW) safe_w = (!st.redo && ob->shadow_distance >= eps) ? shadow_safe_w(r, light, abs_max) : 0.0f;
                float te;
                if (STATS) (FUSED && st.shadow ? n_box_s : n_box)++;
                if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {
@@ -693,6 +715,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   st.pending = 0;
                   st.k = -1;
                   st.shadow = 0;
+                  st.redo = 0;
                   sp = bot = 0;
                   best_obj = -1;
                   best_slot = -1;
@@ -708,6 +731,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                         for (int q = 0; q < 8; q++) d_hist[q] += (q == bin) ? 1u : 0u;
                      }
                      d_ray_trips = 0;
+#pragma unroll
+                     for (int e = 0; e < DIAG_MAIL; e++) d_mail[e] = -1;
                   }
                }
             }
@@ -739,12 +764,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             const float ix = __shfl(r.inv.x, v, 64), iy = __shfl(r.inv.y, v, 64), iz = __shfl(r.inv.z, v, 64);
             const int v_age = CLOSEST ? 0 : __shfl(age, v, 64);
             const int v_shadow = FUSED ? __shfl((int) st.shadow, v, 64) : 0;
+            const int v_redo = MODE == MODE_SHADOW ? __shfl((int) st.redo, v, 64) : 0;
+            const float v_safe_w = MODE == MODE_SHADOW ? __shfl(safe_w, v, 64) : 0.0f;
             if (is_victim) ++bot;
             if (is_thief) {
                st.role = ROLE_HELPER;
                st.owner = v_owner;
                st.k = v_k;
                st.shadow = (unsigned) v_shadow;
+               st.redo = (unsigned) v_redo;
+               safe_w = v_safe_w;
                lim2 = v_lim2;
                r.o = mk3(ox, oy, oz);
                r.d = mk3(dx, dy, dz);
@@ -841,6 +870,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
             lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
             rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
+            if (MODE == MODE_SHADOW && !st.redo) {   // hopeless boxes (device_util.h, shortcut 2); st.plain implies finite boxes
+               const f2 fx = { fmaxf(light.x - na.x, nb.z - light.x), fmaxf(light.x - na.y, nb.w - light.x) };
+               const f2 fy = { fmaxf(light.y - na.z, nc.x - light.y), fmaxf(light.y - na.w, nc.y - light.y) };
+               const f2 fz = { fmaxf(light.z - nb.x, nc.z - light.z), fmaxf(light.z - nb.y, nc.w - light.z) };
+               const f2 far2 = (fx * fx + fy * fy + fz * fz) * 1.0001f + a.light_prune_c;
+               lok = lok && !(d2.x > far2.x);
+               rok = rok && !(d2.y > far2.y);
+            }
          } else {
             // a ray with a zero direction component (1/d infinite) or non-finite data: the reference's own branch
             // structure, so that NaNs fall where they fall there
@@ -850,6 +887,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             if (nd.y != LINK_NONE)
                rok = slab_test(r, nearp, farp, na.y, na.w, nb.y, nb.w, nc.y, nc.w, tr) &&
                      !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > lim2);
+            if (MODE == MODE_SHADOW && !st.redo && a.sc.boxes_finite) {
+               lok = lok && !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > light_far2(light, na.x, na.z, nb.x, nb.z, nc.x, nc.z) * 1.0001f + a.light_prune_c);
+               rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
+            }
          }
          const int le = nd.z > 0 ? ~nd.x : nd.x;   // stack / cursor form of each child: leaf = ~first_slot
          const int re = nd.w > 0 ? ~nd.y : nd.y;
@@ -885,6 +926,23 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          if (CLOSEST) {
             static_assert(LEAF_BATCH == 2, "the pending-face word holds one slot and a flag for the next");
             if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += n_left > 1 ? 2u : 1u;
+            if (STATS > 1) {
+#pragma unroll
+               for (int j = 0; j < 2; j++) {
+                  if (j == 0 || n_left > 1) {
+                     const int f = __float_as_int(q[3 * j].w) + (st.k << 24);
+                     bool seen = false;
+#pragma unroll
+                     for (int e = 0; e < DIAG_MAIL; e++) seen = seen || d_mail[e] == f;
+                     d_repeat += seen ? 1u : 0u;
+                     if (!seen) {
+#pragma unroll
+                        for (int e = 0; e < DIAG_MAIL; e++) d_mail[e] = (e == (int) (d_mail_pos % DIAG_MAIL)) ? f : d_mail[e];
+                        d_mail_pos++;
+                     }
+                  }
+               }
+            }
             const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
             const bool m1 = n_left > 1 && tri_meets(q[3], q[4], q[5], r, eps);
             if (m0 || m1) {
@@ -909,7 +967,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   ob_slot = s + j;
                   ob_key = ~cur;
                   lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
-                  if (MODE == MODE_SHADOW_ANY) {
+                  if (MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {   // device_util.h, shortcut 1
                      stop = true;
                      sp = bot;
                      break;
@@ -956,6 +1014,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          add_stat(a.counters, ST_OUTER_WAVE, d_outer);
          add_stat(a.counters, ST_REFILL, d_refill);
          add_stat(a.counters, 12, d_steal);
+         add_stat(a.counters, 63, d_repeat);
          if (kind != 1) {
    #pragma unroll
             for (int q = 0; q < 8; q++) add_stat(a.counters, ST_TRIP_HIST + (kind ? 8 : 0) + q, d_hist[q]);
@@ -1402,6 +1461,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.mat0 = fuse_mat0;
    a.shadow = nullptr;
    for (int c = 0; c < 3; c++) a.light[c] = fuse_light ? fuse_light[c] : 0.0f;
+   a.light_prune_c = 0.0f;
    a.counters = counters;
    a.count_index = count_index;
    a.cursor_index = cursor_index;
@@ -1456,6 +1516,15 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.light[0] = p.light_origin[0];
    a.light[1] = p.light_origin[1];
    a.light[2] = p.light_origin[2];
+   {   // shortcut 2's constant (device_util.h): a box is skipped when dist(o, box) > far(light, box) + EPSILON + 2 m, squared with
+       // far <= K; m bounds the rounding of the distances (origins lie within |N| * EPSILON of the scene's box)
+      const float l1 = std::fabs(a.light[0]) + std::fabs(a.light[1]) + std::fabs(a.light[2]);
+      const float l2 = std::sqrt(a.light[0] * a.light[0] + a.light[1] * a.light[1] + a.light[2] * a.light[2]);
+      const float m = 1e-5f * (p.sc.scene_abs_max + 3.0f * (p.sc.scene_abs_max + p.sc.max_normal_len * p.sc.epsilon) + l1);
+      const float K = l2 + 1.7320508f * p.sc.scene_abs_max + m;
+      const float e = p.sc.epsilon + 2.0f * m;
+      a.light_prune_c = 2.0f * K * e * 1.001f + e * e;   // NaN (unknown normal lengths, non-finite light) disables the skip
+   }
    a.counters = p.counters;
    a.count_index = CNT_SHADOW;
    a.cursor_index = cursor_index;

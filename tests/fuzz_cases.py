@@ -70,6 +70,52 @@ def random_case(rt, seed):
     return ok, desc
 
 
+def random_grazing_case(rt, seed):
+    """Exact shadows (the light inside the scene's box, so RTStatics.shadowIntersects' own rule runs) over large flat faces with
+    the light IN their plane: the shadow rays of a floor point lie in the floor, every floor face is parallel to them, the
+    triangle test's divisor is rounding noise, and a face that passes reports a point anywhere inside it -- off the ray.
+    The walker's two exact-shadow shortcuts must not assume otherwise (device_util.h)."""
+    rs = np.random.RandomState(9000 + seed)
+    scale = float(rs.choice([0.2, 3.0, 400.0]))
+    y0 = float(rs.uniform(-0.3, 0.0) * scale)
+    n = int(rs.randint(1, 5))                       # floor of n x n quads: few, large faces
+    ext = scale * float(rs.uniform(0.8, 1.5))
+    xs = np.linspace(-ext, ext, n + 1)
+    gx, gz = np.meshgrid(xs, xs, indexing="ij")
+    tilt = float(rs.choice([0.0, 0.0, rs.uniform(-0.2, 0.2)]))     # the floor's plane: y = y0 + tilt * x
+    fv = np.stack([gx.ravel(), y0 + tilt * gx.ravel(), gz.ravel()], axis=1).astype(np.float32)
+    quads = [(a * (n + 1) + b, a * (n + 1) + b + 1, (a + 1) * (n + 1) + b + 1, (a + 1) * (n + 1) + b) for a in range(n) for b in range(n)]
+    fi = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], dtype=np.int32)
+    if rs.rand() < 0.5:                             # and one face spanning the whole floor on top of the others
+        fi = np.concatenate([fi, [[0, n, (n + 1) * (n + 1) - 1]]]).astype(np.int32)
+    objs = [(fv, fi, None, rt.ColorInformation(tuple(rs.uniform(0.3, 1.0, 3))))]
+    for k in range(int(rs.randint(1, 4))):          # things standing on it
+        v, i = rt.meshgen.blob(int(rs.randint(200, 3000)), span=scale * rs.uniform(0.2, 0.6), seed=int(rs.randint(1 << 20)))
+        off = np.array([rs.uniform(-0.6, 0.6) * ext, 0.0, rs.uniform(-0.6, 0.6) * ext])
+        off[1] = y0 + tilt * off[0] - float(v[:, 1].min()) - rs.uniform(0.0, 0.05) * scale    # sunk a little into the floor
+        objs.append(((v + off.astype(np.float32)).astype(np.float32), i, None, rt.ColorInformation(tuple(rs.uniform(0.3, 1.0, 3)))))
+    lx, lz = (rs.uniform(-1.2, 1.2, 2) * ext).astype(np.float32)
+    ly = np.float32(y0 + tilt * float(lx))          # in the floor's plane (as nearly as f32 has it) ...
+    if rs.rand() < 0.3:
+        ly = np.float32(ly + rs.uniform(-1e-4, 1e-4) * scale)   # ... or a hair off it
+    light = dict(origin=(float(lx), float(ly), float(lz)), emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
+    pair = Pair(objs, orientation=(float(rs.uniform(-40, 40)), float(rs.uniform(15, 60)), 0.0), fov=float(rs.uniform(15, 35)),
+                light=light, use_kdtree=bool(rs.rand() < 0.9))
+    W, H, ms = int(rs.randint(60, 140)), int(rs.randint(60, 140)), int(rs.randint(1, 3))
+    cam, ocam, ost = pair.cameras(W, H, ms=ms, seed=seed)
+    cam.createImage()
+    o = dict(pair.oscene.render(ocam, ost, n_threads=8))
+    g = np.nan_to_num(cam._rgb_rows, nan=-1.0)
+    o["rgb"] = np.nan_to_num(o["rgb"], nan=-1.0)
+    ids_equal, w_equal, max_rel, n_diff = compare_frames(g, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
+    ok = ids_equal and w_equal and max_rel <= 1e-3
+    floor_frac = float((o["hit_obj"] == 0).mean())
+    desc = "grazing seed %d scale %g floor %dx%d tilt %.2f objs %d %dx%dx%d floor pixels %.2f: %s (ids %s w %s rel %.2e diff %d)" % (
+        seed, scale, n, n, tilt, len(objs), W, H, ms, floor_frac, "ok" if ok else "MISMATCH", ids_equal, w_equal, max_rel, n_diff)
+    pair.close()
+    return ok, desc
+
+
 def random_analytic_case(rt, seed):
     """The same with the analytic objects of the reference's Whitted / Cornell scenes: planes, spheres, an optional mesh;
     plain / mirror / refraction / checkerboard / BRDF materials (bounce chains through glass and mirrors)."""

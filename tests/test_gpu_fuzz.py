@@ -33,3 +33,14 @@ def test_random_ray_batches_match_the_oracle(rt, orc):
         if not ok:
             failures.append(desc)
     assert not failures, "\n".join(failures)
+
+
+def test_random_grazing_shadow_scenes_match_the_oracle(rt, orc):
+    """Exact shadows with the light in the plane of large floor faces (hit points off the ray): fuzz_cases.random_grazing_case."""
+    from fuzz_cases import random_grazing_case
+    failures = []
+    for seed in range(32):
+        ok, desc = random_grazing_case(rt, seed)
+        if not ok:
+            failures.append(desc)
+    assert not failures, "\n".join(failures)

@@ -26,6 +26,7 @@ for lm, name in ((rt.LightingModel(), "primary only"), (rt.PhongLightingModel(li
     names = ["primary", "shadow", "secondary", "box", "tri", "hits", "node_lane", "node_wave", "leaf_lane", "leaf_wave", "outer", "refill"]
     print(name, dict(zip(names, d)))
     print("  steals %d; longest wave %.2f ms, mean wave %.2f ms, mean time after queue dry %.2f ms (waves of LAST walker launch sets; sums over launches)" % (d[12], d[13] / 1e5, d[14] / 1e5 / (6 * 256 * 4), d[15] / 1e5 / (6 * 256 * 4)))
+    print("  triangle tests that repeat one of the ray's last 8 distinct faces (owner lanes and helpers, each with its own list): %d of %d" % (d[63], d[4]))
     print("  node-phase lane util %.3f  leaf-phase lane util %.3f  node trips/outer %.1f leaf trips/outer %.1f" % (
         d[6] / max(64.0 * d[7], 1), d[8] / max(64.0 * d[9], 1), d[7] / max(d[10], 1), d[9] / max(d[10], 1)))
     M = (1 << 64) - 1
