@@ -3,23 +3,36 @@
 
 A "step" is one frame: every primary sample of the 1080p image, one shadow ray per hit sample,
 shaded, averaged and written.  The scene (flattened hierarchy) is resident in HBM before the timed
-region; the framebuffer stays in HBM.  With N > 1 GPUs (one process per GPU, launched by
-torch.distributed.run) the frame's 16x16-pixel tiles are interleaved over the ranks, the scene is
-replicated, and the step ends with ONE gather of the tiles to rank 0 over RCCL (strong scaling:
-the frame is fixed).  Rays are counted by the kernel, not assumed.
+region; the framebuffer stays in HBM.  Rays are counted by the kernel, not assumed.
 
-Prints ONE JSON line on rank 0 (see the repository's bench contract) with two extra objects:
-  roofline     -- the dominant kernel (the primary-ray walker): its algorithmic bytes per launch / its
-                  average launch duration, from HIP events the library records around every kernel on
-                  the stream it launches on, over the timed region, vs 8 TB/s
-  cpu_baseline -- the oracle (C restatement of the reference's algorithm, reference visit order) timed
-                  on this host's cores on a bounded sample of the same frame.
+N > 1 GPUs: one process per GPU.  `python bench.py --gpus N` starts the N ranks ITSELF when it was not
+started by torch.distributed.run (WORLD_SIZE unset): the parent touches no GPU, spawns N children with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line and fails if any child fails -- the
+reference's own fan-out over availableProcessors() threads (Camera.java:129-182), as processes.  The
+frame's 16x16-pixel tiles are interleaved over the ranks, the scene is replicated, every rank renders
+its tiles straight into one compact block and the step ends with ONE gather of the blocks to rank 0
+over RCCL plus one unpack kernel there (strong scaling: the frame is fixed).
+`--dry-run-gloo` rehearses exactly that launch and exchange on CPUs (gloo, library-shaped blocks, no
+rendering): it is how the N-rank path is tested where there is no GPU.
+
+Prints ONE JSON line on rank 0 (see the repository's bench contract) with extra objects:
+  roofline        the dominant kernel: its algorithmic bytes per launch / its average launch duration,
+                  from HIP events the library records around every kernel on the stream it launches on,
+                  over the timed region, vs 8 TB/s
+  cpu_baseline    the oracle (C restatement of the reference's algorithm, reference visit order) timed
+                  on this host's cores -- all the process may use -- on a bounded sample of the same frame
+  pipelined       the same frames with two in flight per rank (exchange of frame k under frame k + 1)
+  blocking_render the drop-in seam itself: wall time of the blocking mi355rt_render into page-locked
+                  host buffers (N = 1)
+  soup            SURVEY 8(d)'s adversarial second input: a uniform triangle soup of the same face count
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,45 +49,175 @@ BYTES_PER_TRI_TEST = 48          # 3 x float4 positions
 BYTES_PER_HIT = 48               # 3 x float4 normals per final hit
 BYTES_PER_PIXEL = 16             # f32 RGB + i32 id written
 
+# <base dir> layout of the reference's README.txt:10-15 (RayTracer.java:117-140)
+MODEL_FILES = {"bunny": "bunny/reconstruction/bun_zipper.ply", "dragon": "dragon_recon/dragon_vrip.ply",
+               "buddha": "happy_recon/happy_vrip.ply", "lucy": "lucy.ply", "thai": "xyzrgb_statuette.ply/data"}
 
-def main():
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="dragon", help="stand-in from meshgen.STANFORD")
     ap.add_argument("--faces", type=int, default=0, help="override the face count (0 = the model's own)")
+    ap.add_argument("--models-dir", default="", help="base dir laid out as the reference's README.txt:10-15: render the real PLY instead of the stand-in")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the blocking_render and soup objects (profiling runs)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="tuning aid (single process): render only rank 0's tiles of an N-rank run; the line is not a bench result")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="extra 'pipelined' figure (N = 1 only): frames rendered with this many in flight; 1 = skip")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="the 'pipelined' figure: frames in flight per rank; 1 = skip")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="CPU rehearsal of the N-rank launch and exchange: gloo, library-shaped blocks, no GPU, no rendering")
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """The parent of an N-rank run.  It makes no torch.cuda / HIP call that initialises a GPU (device_count does not, on
+    this image): a process that has touched the GPU must not be replaced or forked into rank processes."""
+    n = args.gpus
+    if not args.dry_run_gloo:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report a %d-GPU number from fewer GPUs\n"
+                             % (n, have, n))
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    rank0_out = tempfile.TemporaryFile(mode="w+")   # a file, not a pipe: nothing can block on a full pipe while the parent polls
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=rank0_out if r == 0 else sys.stderr))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.05)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = (r, p.returncode)
+    if failed is not None:
+        for p in procs:   # the exact processes started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        sys.stderr.write("bench.py: rank %d exited with status %d; no result\n" % failed)
+        return 1
+    rank0_out.seek(0)
+    out = rank0_out.read()
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON lines\n%s\n" % (len(lines), out))
+        return 1
+    print(lines[0])
+    return 0
+
+
+def dry_run_gloo(args, rank, world):
+    """The N-rank path without GPUs: every rank fills its compact block (the layout the library's kernels write with
+    settings.tile_compact) from one seeded synthetic frame, the blocks are gathered with gloo, rank 0 unpacks them and
+    must hold the whole frame.  Frames in flight use the same double-buffered async path as the GPU run."""
+    from ray_tracer_amd import tiles
+    if world == 1 and "MASTER_PORT" not in os.environ:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    W, H, T = args.width, args.height, tiles.DEFAULT_TILE
+    g = torch.Generator().manual_seed(2024)
+    full = (torch.rand(H, W, 3, generator=g), torch.randint(-1, 871414, (H, W), generator=g, dtype=torch.int32),
+            torch.randint(-1, 2, (H, W), generator=g, dtype=torch.int32), torch.rand(H, W, generator=g))
+    D = max(1, args.frames_in_flight)
+    sh = tiles.TileSharder(W, H, rank, world, T, "cpu", n_buffers=D)
+    outs = [[torch.full_like(t, -7) for t in full] for _ in range(D)]
+    pending = [None] * D
+    t0 = time.perf_counter()
+    for k in range(max(args.steps, D)):
+        b = k % D
+        if pending[b]:
+            pending[b]()
+        tiles.tiles_pack_reference(full[0], full[1], full[2], full[3], rank, world, T, sh.blocks[b])   # stands in for the render
+        pending[b] = sh.gather(*outs[b], buffer=b, async_op=True)
+    for f in pending:
+        if f:
+            f()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ranks = dist.get_world_size()
+    if rank == 0:
+        same = all(torch.equal(a, b) for o in outs for a, b in zip(o, full))
+        print(json.dumps({"metric": "Mrays/sec (primary+shadow) on Dragon 1080p", "value": None, "unit": "Mrays/s", "dry_run": True,
+                          "backend": "gloo", "n_gpus": args.gpus, "ranks": ranks, "steps": args.steps, "frames_in_flight": D,
+                          "gathered_frame_equals_single_gpu_frame": bool(same), "block_bytes_per_rank": 4 * tiles.PLANES * sh.n,
+                          "exchange_s": round(dt, 3), "note": "launch + exchange rehearsal on CPUs: nothing was rendered or timed"}))
+    dist.destroy_process_group()
+    return 0
+
+
+def load_model(rt, args):
+    cfg = rt.meshgen.STANFORD[args.model]
+    if args.models_dir:
+        path = os.path.join(args.models_dir, MODEL_FILES[args.model])
+        if not os.path.exists(path):
+            raise SystemExit("bench.py: %s not found (--models-dir must be laid out as the reference's README.txt:10-15)" % path)
+        v, i, n = rt.load_ply(path)
+        return cfg, v, i, n, "%s (%s)" % (args.model, path)
+    v, i = rt.meshgen.stanford_standin(args.model, args.faces or None)
+    label = "configs[1]: Dragon" if args.model == "dragon" and not args.faces else args.model
+    return cfg, v, i, None, "%s stand-in (seeded procedural blob, %d faces)" % (label, i.shape[0])
+
+
+def stats_of(ms):
+    a = np.asarray(ms, dtype=np.float64)
+    return {"mean": round(float(a.mean()), 4), "median": round(float(np.median(a)), 4), "min": round(float(a.min()), 4),
+            "max": round(float(a.max()), 4)}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or with --nproc-per-node N" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run_gloo:
+        sys.exit(dry_run_gloo(args, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     import ray_tracer_amd as rt
     from ray_tracer_amd import tiles
 
-    cfg = rt.meshgen.STANFORD[args.model]
-    verts, idx = rt.meshgen.stanford_standin(args.model, args.faces or None)
+    cfg, verts, idx, normals, label = load_model(rt, args)
     light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))          # RayTracer.java:106
-    mesh = rt.TriangleMesh((verts, idx), rt.ColorInformation((0.9, 0.9, 0.9)), True)  # RayTracer.java:122-123
+    mesh = rt.TriangleMesh((verts, idx) if normals is None else (verts, idx, normals), rt.ColorInformation((0.9, 0.9, 0.9)), True)  # RayTracer.java:122-123
     t0 = time.time()
     scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"], device=local_rank)
     build_s = time.time() - t0
@@ -83,16 +226,21 @@ def main():
 
     rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     hit_id = torch.zeros((H, W), dtype=torch.int32, device=dev)
+    hit_obj = torch.zeros((H, W), dtype=torch.int32, device=dev)
     hit_w = torch.zeros((H, W), dtype=torch.float32, device=dev)
-    frame = rt._abi.Frame(rgb.data_ptr(), None, hit_id.data_ptr(), None, hit_w.data_ptr())
+    frame = rt._abi.Frame(rgb.data_ptr(), None, hit_id.data_ptr(), hit_obj.data_ptr(), hit_w.data_ptr())
     sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev)
     stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream
 
     tile_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
+    target = frame if world == 1 else sharder.blocks[0].frame()   # N > 1: this rank's tiles, compact, ready to send
 
     def step(stats=False, times=False):
-        cam.render_device(frame, stream=stream, tile_rank=rank, tile_world=tile_world, tile_size=tiles.DEFAULT_TILE,
-                          collect_stats=stats, collect_times=times)
+        cam.render_device(target, stream=stream, tile_rank=rank, tile_world=tile_world, tile_size=tiles.DEFAULT_TILE,
+                          collect_stats=stats, collect_times=times, tile_compact=world > 1)
+
+    def exchange():
+        sharder.gather(rgb, hit_id, hit_obj, hit_w)
 
     # counted, not assumed: one instrumented frame
     step(stats=True)
@@ -109,35 +257,63 @@ def main():
 
     for _ in range(args.warmup):
         step(times=True)
-        sharder.gather(rgb, hit_w, hit_id)
+        exchange()
     torch.cuda.synchronize()
     cam.kernel_profile(reset=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
         step(times=True)
         ev[k][1].record()
-        sharder.gather(rgb, hit_w, hit_id)
+        exchange()
+        ev[k][2].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    frame_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # all kernels of one frame, this rank
+    render_ms = [a.elapsed_time(b) for a, b, _ in ev]     # all kernels of one frame, this rank
+    step_ms = [a.elapsed_time(c) for a, _, c in ev]       # with this rank's part of the exchange
+    frame_ms = float(np.mean(render_ms))
     kprof = cam.kernel_profile()
+    rank_ms = [frame_ms]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        mine = torch.tensor([frame_ms], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) for t in every]
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_per_frame / (elapsed / args.steps) / 1e6
 
-    if rank != 0:
+    # Not the headline: the same frames with two in flight per rank (a second scene handle, stream and block); the
+    # exchange of frame k runs under the render of frame k + 1.  Every launch of the pipeline ends on its longest rays
+    # with the chip draining; the next frame's bulk fills that in.  All ranks take part (the gathers are collectives).
+    pipelined = None
+    if tile_world == world and args.frames_in_flight > 1:
+        pipelined = frames_in_flight(rt, tiles, args, mesh, light, cfg, dev, rank, world, W, H, rays_per_frame)
+
+    # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
+    frame_verified = None
+    if world > 1 and rank == 0:
+        single = [torch.zeros_like(t) for t in (rgb, hit_id, hit_obj, hit_w)]
+        whole = rt._abi.Frame(single[0].data_ptr(), None, single[1].data_ptr(), single[2].data_ptr(), single[3].data_ptr())
+        cam.render_device(whole, stream=stream, tile_rank=0, tile_world=1, tile_size=tiles.DEFAULT_TILE)
+        torch.cuda.synchronize()
+        frame_verified = all(bool(torch.equal(a, b)) for a, b in zip(single, (rgb, hit_id, hit_obj, hit_w)))
+        if pipelined:
+            pipelined_equal = pipelined.pop("_frames_equal")(single)
+            frame_verified = frame_verified and pipelined_equal
+
+    if rank != 0:   # every collective is behind us: the rest is rank 0's bookkeeping
         if world > 1:
             dist.destroy_process_group()
         return
@@ -151,7 +327,7 @@ def main():
             v.update(rays=kcounts[name]["rays"], box_tests=kcounts[name]["box_tests"], tri_tests=kcounts[name]["tri_tests"])
     dom = max(kernels, key=lambda n: kernels[n]["ms_per_frame"])
     lp, ls, lsec, lb, lt, lh = [float(x) for x in local_counts.tolist()]
-    own_pixels = float(sharder.my_pix.ge(0).sum().item())
+    own_pixels = float((tiles.tile_pixels(W, H, tiles.owned_tiles(W, H, rank, tile_world, tiles.DEFAULT_TILE), tiles.DEFAULT_TILE) >= 0).sum().item())
     frame_bytes = BYTES_PER_BOX_TEST * lb + BYTES_PER_TRI_TEST * lt + BYTES_PER_HIT * lh + BYTES_PER_PIXEL * own_pixels
     kc = dict(kcounts[dom])
     # MODE_FUSED: the primary launch walked the shadow rays too (no shadow launch); their tests belong to it
@@ -178,11 +354,17 @@ def main():
         except Exception:
             traffic = None
     dom_rays = max(kc["rays"] / n_launch, 1.0)
+    exact_shadow = dom == "walk_shadow" and not shadow_any_hit_proven(scene, light)
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                # the memory side's own figure, from the PMC counters of profiles/ (per launch, when a profile of this workload
+                # is there): what the kernel really moves from HBM -- the rest of the algorithmic bytes are L2 / MALL hits
+                "hbm_measured_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic else None,
+                "hbm_measured_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "kernel": "walk_kernel<0,MODE_FUSED> (primary rays, each hit's shadow ray walked by the same lane)" if fused else
                           {"walk_primary": "walk_kernel<0,MODE_CLOSEST> (primary rays)",
-                           "walk_shadow": "walk_kernel<0,MODE_SHADOW_ANY> (shadow rays)"}.get(dom, dom),
+                           "walk_shadow": "walk_kernel<0,MODE_SHADOW> (shadow rays, the reference's closest-hit form)" if exact_shadow
+                                          else "walk_kernel<0,MODE_SHADOW_ANY> (shadow rays)"}.get(dom, dom),
                 "kernel_ms": dom_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "rays_per_launch": dom_rays, "bytes_per_ray": round(algo_bytes / dom_rays, 1),
                 "box_tests_per_ray": round(kc["box_tests"] / n_launch / dom_rays, 2),
@@ -190,43 +372,40 @@ def main():
                 "frame": {"gpu_ms": round(frame_ms, 4), "algorithmic_bytes": frame_bytes,
                           "achieved_GBs": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 2), "kernels": kernels}}
 
-    # Not the headline: the same frames with two in flight (a second scene handle and stream).  Every launch of the
-    # pipeline ends on its longest rays with the chip draining; the next frame's bulk fills that in.  `value` above stays
-    # the one-frame-at-a-time number the roofline figures belong to.
-    pipelined = None
-    if world == 1 and tile_world == 1 and args.frames_in_flight > 1:
-        pipelined = frames_in_flight(rt, args, mesh, light, cfg, dev, W, H, rays_per_frame)
-
-    # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
-    frame_verified = None
-    if world > 1:
-        rgb1, id1, w1 = torch.zeros_like(rgb), torch.zeros_like(hit_id), torch.zeros_like(hit_w)
-        whole = rt._abi.Frame(rgb1.data_ptr(), None, id1.data_ptr(), None, w1.data_ptr())
-        cam.render_device(whole, stream=stream, tile_rank=0, tile_world=1, tile_size=tiles.DEFAULT_TILE)
-        torch.cuda.synchronize()
-        frame_verified = bool(torch.equal(rgb1, rgb) and torch.equal(id1, hit_id) and torch.equal(w1, hit_w))
+    blocking = soup = None
+    if world == 1 and tile_world == 1 and not args.no_extras:
+        blocking = blocking_render(rt, cam, rays_per_frame)
+        if args.model == "dragon" and not args.models_dir:
+            soup = soup_line(rt, args, light, cfg, dev, W, H)
 
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, verts, idx, cfg, light)
+        cpu = cpu_baseline(args, verts, idx, normals, cfg, light)
 
     out = {
         "metric": "Mrays/sec (primary+shadow) on Dragon 1080p",
-        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s stand-in (seeded procedural blob, %d faces) %dx%d, %d spp, Phong, primary+shadow"
-                               % ("configs[1]: Dragon" if args.model == "dragon" and not args.faces else args.model, idx.shape[0], W, H, args.spp),
+        "dtype": "f32", "data": "synthetic" if not args.models_dir else "PLY file",
+        "config": {"workload": "%s %dx%d, %d spp, Phong, primary+shadow" % (label, W, H, args.spp),
                    "rays_per_frame": int(rays_per_frame), "primary": int(primary), "shadow": int(shadow),
                    "tile": tiles.DEFAULT_TILE, "parallelism": "tiles%d" % world,
                    "hierarchy": {k: scene.object_info(0)[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")},
                    "scene_hbm_bytes": scene.device_bytes(), "scene_build_s": round(build_s, 2)},
+        # per step, from HIP events on this rank's stream: the frame's kernels alone, and with this rank's part of the exchange
+        "step_gpu_ms": {"render": stats_of(render_ms), "render_and_exchange": stats_of(step_ms)},
+        "rank_render_ms": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "all": [round(x, 4) for x in rank_ms]},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     if pipelined:
         out["pipelined"] = pipelined
+    if blocking:
+        out["blocking_render"] = blocking
+    if soup:
+        out["soup"] = soup
     if frame_verified is not None:
-        out["config"]["gathered_frame_equals_single_gpu_frame"] = frame_verified
+        out["gathered_frame_equals_single_gpu_frame"] = frame_verified
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
     print(json.dumps(out))
@@ -234,41 +413,158 @@ def main():
         dist.destroy_process_group()
 
 
-def frames_in_flight(rt, args, mesh, light, cfg, dev, W, H, rays_per_frame):
-    """K frames with D in flight: D scene handles (each owns its scratch) on D streams, round robin, no host sync between."""
+def shadow_any_hit_proven(scene, light):
+    """Whether the frame's shadow rays ran the any-hit form (far light) or the reference's closest-hit form: mirrors the
+    library's own test only for the label in the JSON line."""
+    mm = scene.object_info(0)["minmax"]
+    lo, hi = mm[:3], mm[3:]
+    diag = float(np.linalg.norm(hi - lo))
+    d = np.maximum(np.maximum(lo - np.array(light.origin), np.array(light.origin) - hi), 0.0)
+    return float(np.linalg.norm(d)) > 1.01 * diag
+
+
+def frames_in_flight(rt, tiles, args, mesh, light, cfg, dev, rank, world, W, H, rays_per_frame):
+    """K frames with D in flight on every rank: D scene handles (each owns its scratch) on D streams, round robin, no host
+    sync between; with N > 1 each frame's block is gathered asynchronously and unpacked on rank 0 when its buffer comes
+    round again, so the exchange of frame k runs under the render of frame k + 1."""
     D = args.frames_in_flight
     scenes = [rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"], device=dev.index) for _ in range(D)]
     cams = [rt.Camera(s, args.spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024) for s in scenes]
     streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
-    bufs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(D)]
-    frames = [rt._abi.Frame(b.data_ptr(), None, None, None, None) for b in bufs]
+    sh = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev, n_buffers=D)
+    full = rank == 0
+    outs = [[torch.zeros((H, W, 3), dtype=torch.float32, device=dev), torch.zeros((H, W), dtype=torch.int32, device=dev),
+             torch.zeros((H, W), dtype=torch.int32, device=dev), torch.zeros((H, W), dtype=torch.float32, device=dev)] if (full or world == 1)
+            else [None] * 4 for _ in range(D)]
+    frames = [rt._abi.Frame(o[0].data_ptr(), None, o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr()) if world == 1 else sh.blocks[b].frame()
+              for b, o in enumerate(outs)]
+    pending = [None] * D
 
     def run(n):
         for k in range(n):
-            cams[k % D].render_device(frames[k % D], stream=streams[k % D].cuda_stream)
+            b = k % D
+            with torch.cuda.stream(streams[b]):
+                if pending[b]:
+                    pending[b]()   # frame k - D: wait for its gather (stream-side), unpack on rank 0; then the block is free again
+                cams[b].render_device(frames[b], stream=streams[b].cuda_stream, tile_rank=rank, tile_world=world,
+                                      tile_size=tiles.DEFAULT_TILE, tile_compact=world > 1)
+                pending[b] = sh.gather(*outs[b], buffer=b, async_op=True) if world > 1 else None
+
+    def drain():
+        for b in range(D):
+            if pending[b]:
+                with torch.cuda.stream(streams[b]):
+                    pending[b]()
+                pending[b] = None
+        torch.cuda.synchronize()
 
     run(2 * D)
-    torch.cuda.synchronize()
+    drain()
+    if world > 1:
+        dist.barrier()
     n = max(args.steps, 2 * D)
     t0 = time.perf_counter()
     run(n)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
-    same = all(bool(torch.equal(bufs[0], b)) for b in bufs[1:])
+    drain()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    dt /= n
+    same = all(bool(torch.equal(a, b)) for o in outs[1:] for a, b in zip(o, outs[0])) if (full or world == 1) else None
     for s in scenes:
         s.close()
-    return {"frames_in_flight": D, "steps": n, "ms_per_step": round(dt * 1e3, 4), "value": round(rays_per_frame / dt / 1e6, 2),
-            "unit": "Mrays/s", "frames_identical": same,
-            "note": "not the headline value: frames overlap, so a frame's launch tails are filled by the next frame's bulk"}
+    res = {"frames_in_flight": D, "steps": n, "ms_per_step": round(dt * 1e3, 4), "value": round(rays_per_frame / dt / 1e6, 2),
+           "unit": "Mrays/s", "frames_identical": same,
+           "note": "not the headline value: frames overlap, so a frame's launch tails (and, with N > 1, its exchange) are filled by the next frame's bulk"}
+    if world > 1 and full:
+        res["_frames_equal"] = lambda single: all(bool(torch.equal(a, b)) for a, b in zip(single, outs[0]))
+    return res
 
 
-def cpu_baseline(args, verts, idx, cfg, light):
+def blocking_render(rt, cam, rays_per_frame, n=10):
+    """Wall time of the drop-in call itself, Camera.createImage() -> mi355rt_render: the frame's kernels, the device-to-host
+    copies of rgb / hit_id / hit_obj / hit_w into ONE page-locked set of arrays (as Camera.pixels is one array), the host
+    mirror's listener event."""
+    cam.pinOutput(True)
+    try:
+        cam.createImage()
+        ms = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            cam.createImage()
+            ms.append((time.perf_counter() - t0) * 1e3)
+    finally:
+        cam.pinOutput(False)
+    med = float(np.median(ms))
+    return {"call": "mi355rt_render (blocking, host outputs rgb + hit_id + hit_obj + hit_w, page-locked)", "frames": n, "ms": stats_of(ms),
+            "value": round(rays_per_frame / (med * 1e-3) / 1e6, 2), "unit": "Mrays/s",
+            "bytes_to_host": cam.screenWidth * cam.screenHeight * 24,
+            "note": "PCIe-inclusive: never the headline value"}
+
+
+def soup_line(rt, args, light, cfg, dev, W, H, steps=5):
+    """SURVEY 8(d)'s adversarial second input: a uniform random triangle soup of the same face count in the same box, same
+    camera, light and settings -- no surface coherence, so rays walk many more leaves before anything stops them."""
+    v, i = rt.meshgen.soup(rt.meshgen.STANFORD["dragon"]["faces"], span=cfg["span"], tri_size=0.004, seed=11)
+    mesh = rt.TriangleMesh((v, i), rt.ColorInformation((0.9, 0.9, 0.9)), True)
+    scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"], device=dev.index)
+    cam = rt.Camera(scene, args.spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
+    rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    frame = rt._abi.Frame(rgb.data_ptr(), None, None, None, None)
+    cam.render_device(frame, collect_stats=True)
+    torch.cuda.synchronize()
+    st = cam.frame_stats()
+    rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
+    for _ in range(2):
+        cam.render_device(frame)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cam.render_device(frame)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    info = scene.object_info(0)
+    scene.close()
+    return {"workload": "uniform triangle soup, %d faces (edge %.3g of the span), same box / camera / light / %dx%d / %d spp"
+                        % (i.shape[0], 0.004, W, H, args.spp),
+            "steps": steps, "ms_per_step": round(dt * 1e3, 4), "value": round(rays / dt / 1e6, 2), "unit": "Mrays/s",
+            "rays_per_frame": int(rays), "box_tests_per_ray": round(st["box_tests"] / rays, 1), "tri_tests_per_ray": round(st["tri_tests"] / rays, 1),
+            "hierarchy": {k: info[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")}}
+
+
+def usable_cores():
+    """Cores this process may use: its affinity mask, cut down by a cgroup CPU quota where one is set."""
+    affinity = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    return affinity, quota
+
+
+def cpu_baseline(args, verts, idx, normals, cfg, light):
     """The oracle in reference order (exhaustive both-children traversal), multithreaded, on a bounded
-    sample of the same frame: every k-th pixel in row-major order, all of its samples and shadow rays."""
+    sample of the same frame: every k-th pixel in row-major order, all of its samples and shadow rays.
+    Threads: every core the process may use (the reference starts availableProcessors() threads, Camera.java:129)."""
     import oracle
     import ray_tracer_amd as rt
-    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16"))))
-    osc = oracle.OracleScene([(verts, idx, None, oracle.material(diffuse=(0.9, 0.9, 0.9)))])
+    affinity, quota = usable_cores()
+    threads = args.cpu_threads or max(1, min(affinity, int(np.ceil(quota)) if quota else affinity))
+    osc = oracle.OracleScene([(verts, idx, normals, oracle.material(diffuse=(0.9, 0.9, 0.9)))])
     ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, args.width, args.height)
     ost = oracle.settings(epsilon=osc.epsilon(), ms=args.spp, lighting=1, seed=2024, light_origin=light.origin,
                           light_emission=light.emission, light_ambient=light.ambient)
@@ -276,7 +572,7 @@ def cpu_baseline(args, verts, idx, cfg, light):
     # a strided subset of the frame when the whole frame would take longer, else the whole frame, repeated
     stride = 257
     t0 = time.perf_counter()
-    o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
+    o = osc.render(ocam, ost, n_threads=threads, pixel_stride=stride, want_stats=True)
     dt = max(time.perf_counter() - t0, 1e-4)
     full_s = dt * stride
     stride = max(1, int(np.ceil(full_s / args.cpu_seconds)))
@@ -286,7 +582,7 @@ def cpu_baseline(args, verts, idx, cfg, light):
     repeats = 0
     t0 = time.perf_counter()
     while True:   # at least one pass over the sample, then more until about --cpu-seconds have gone
-        o = osc.render(ocam, ost, n_threads=cores, pixel_stride=stride, want_stats=True)
+        o = osc.render(ocam, ost, n_threads=threads, pixel_stride=stride, want_stats=True)
         s = o["stats"]
         rays += s["primary_rays"] + s["shadow_rays"] + s["secondary_rays"]
         repeats += 1
@@ -294,10 +590,12 @@ def cpu_baseline(args, verts, idx, cfg, light):
         if dt * (repeats + 1) / repeats > args.cpu_seconds or repeats >= 64:
             break
     osc.close()
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "threads": threads, "cores_available": affinity,
+            "cgroup_cpu_quota": quota, "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"), "kind": "port",
             "sample": "every %d-th pixel of the same %dx%d frame, %d spp + shadow rays, rendered %d time(s) (%d rays, %.1f s); "
-                      "C restatement of the Java algorithm in reference visit order, %d pthreads"
-                      % (stride, args.width, args.height, args.spp, repeats, rays, dt, cores),
+                      "C restatement of the Java algorithm in reference visit order, %d pthreads (all the cores the process may use: "
+                      "affinity %d, cgroup quota %s)"
+                      % (stride, args.width, args.height, args.spp, repeats, rays, dt, threads, affinity, quota),
             "java_present": bool(any(os.path.exists(os.path.join(p, "java")) for p in os.environ.get("PATH", "").split(":")))}
 
 

@@ -21,8 +21,9 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 5   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
-                                 * 4: mi355rt_render_device_noalloc; 5: mi355rt_render returns hit_obj, mi355rt_mesh_desc.compute_kdtree */
+#define MI355RT_ABI_VERSION 6   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
+                                 * 4: mi355rt_render_device_noalloc; 5: mi355rt_render returns hit_obj, mi355rt_mesh_desc.compute_kdtree;
+                                 * 6: mi355rt_settings.tile_compact, mi355rt_tiles_unpack_device */
 
 enum {
    MI355RT_OK = 0,
@@ -115,6 +116,11 @@ typedef struct {
    int32_t collect_stats;       /* bit mask: MI355RT_COLLECT_COUNTS (count rays / box tests / triangle tests; slower; see
                                  * mi355rt_frame_stats), MI355RT_COLLECT_TIMES (HIP events around every kernel; see
                                  * mi355rt_kernel_profile) */
+   int32_t tile_compact;        /* != 0 (mi355rt_render_device only): the frame's arrays are in tile-compact order -- pixel (x, y)
+                                 * of this rank's k-th owned tile (tile t = tile_rank + k * tile_world) is element
+                                 * k * tile_size^2 + (y mod tile_size) * tile_size + (x mod tile_size); pixels of a tile that hang
+                                 * off the image are not written.  It is the form the one exchange step of a multi-GPU frame
+                                 * sends as it is (mi355rt_tiles_unpack_device puts it back in image order) */
 } mi355rt_settings;
 
 typedef struct {
@@ -242,6 +248,15 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
 #define MI355RT_NOALLOC_SCRATCH_BYTES (128u << 20)
 int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings,
                                   const mi355rt_frame *frame, void *hip_stream);
+
+/* Multi-GPU frames (the reference's own fan-out is Camera.java:129-182, pixels scattered over threads).
+ * Each rank renders its tiles with settings.tile_compact into ONE block of 6 n words, n = slots_per_rank * tile_size^2,
+ * laid out [rgb: 3 n][hit_id: n][hit_obj: n][hit_w: n] (mi355rt_frame pointers at those offsets; slots_per_rank =
+ * ceil(number of tiles / world), the same on every rank); the blocks are gathered to one rank (RCCL); this call, on that
+ * rank, scatters `world` consecutive blocks at blocks_dev back into image order.  Device pointers on the current
+ * device, asynchronous on hip_stream; any pointer of `frame` may be NULL (argb8 is not produced). */
+int mi355rt_tiles_unpack_device(const float *blocks_dev, int32_t world, int32_t slots_per_rank, int32_t tile_size, int32_t width,
+                                int32_t height, const mi355rt_frame *frame, void *hip_stream);
 
 /* Counters of the most recent render on this scene that ran with settings.collect_stats != 0
  * (blocking: synchronises the scene's device). */

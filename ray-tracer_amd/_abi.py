@@ -62,7 +62,7 @@ class Settings(C.Structure):
                 ("max_mirror_bounces", C.c_int32), ("rng_seed", C.c_uint64),
                 ("light_origin", C.c_float * 3), ("light_emission", C.c_float * 3),
                 ("light_ambient", C.c_float * 3), ("tile_size", C.c_int32), ("tile_rank", C.c_int32),
-                ("tile_world", C.c_int32), ("collect_stats", C.c_int32)]
+                ("tile_world", C.c_int32), ("collect_stats", C.c_int32), ("tile_compact", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -102,6 +102,7 @@ PROTOTYPES = {
     "mi355rt_host_free": (C.c_int, [C.c_void_p]),
     "mi355rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
     "mi355rt_render_device_noalloc": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(Frame), C.c_void_p]),
+    "mi355rt_tiles_unpack_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Frame), C.c_void_p]),
     "mi355rt_frame_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "mi355rt_kernel_profile": (C.c_int, [C.c_void_p, C.POINTER(KernelProfile), C.c_int]),
     "mi355rt_image_argb8": (C.c_int, [c_float_p, C.c_int32, C.c_int32, C.c_int, c_uint32_p, C.c_int32]),

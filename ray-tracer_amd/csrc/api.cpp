@@ -597,6 +597,7 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.micro_per_tile = (tile / 8) * (tile / 8);
    n_micro = owned * p.micro_per_tile;
    if (n_micro > 0x3fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups");
+   p.tile_compact = st->tile_compact != 0 ? 1 : 0;
    p.stats = (st->collect_stats & (MI355RT_COLLECT_COUNTS | MI355RT_COLLECT_DIAG)) != 0;
    p.diag = (st->collect_stats & MI355RT_COLLECT_DIAG) != 0;
    return MI355RT_OK;
@@ -1176,12 +1177,29 @@ int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *ca
    });
 }
 
+int mi355rt_tiles_unpack_device(const float *blocks_dev, int32_t world, int32_t slots_per_rank, int32_t tile_size, int32_t width, int32_t height,
+                                const mi355rt_frame *frame, void *hip_stream)
+{
+   return guarded([&]() -> int {
+      if (!blocks_dev || !frame) return fail(MI355RT_E_ARG, "null argument");
+      if (world < 1 || slots_per_rank < 0 || width < 1 || height < 1) return fail(MI355RT_E_ARG, "sizes must be positive");
+      if (tile_size < 8 || tile_size % 8 != 0 || tile_size > 4096) return fail(MI355RT_E_ARG, "tile_size must be a multiple of 8 in [8, 4096]");
+      const long long tiles = (long long) ((width + tile_size - 1) / tile_size) * ((height + tile_size - 1) / tile_size);
+      if ((long long) slots_per_rank != (tiles + world - 1) / world)
+         return fail(MI355RT_E_ARG, "slots_per_rank must be ceil(tiles / world) = " + std::to_string((tiles + world - 1) / world));
+      HIP_TRY(launch_tiles_unpack(blocks_dev, world, slots_per_rank, tile_size, width, height, frame->rgb, frame->hit_id, frame->hit_obj,
+                                  frame->hit_w, (hipStream_t) hip_stream));
+      return MI355RT_OK;
+   });
+}
+
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
                    int32_t *hit_id_out, int32_t *hit_obj_out, float *hit_w_out)
 {
    return guarded([&]() -> int {
       if (!scene || !cam || !settings) return fail(MI355RT_E_ARG, "null argument");
       if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+      if (settings->tile_compact) return fail(MI355RT_E_ARG, "tile_compact is for mi355rt_render_device (this call returns whole frames in image order)");
       DeviceScope scope(scene->device);
       if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
       const size_t pixels = (size_t) cam->width * (size_t) cam->height;

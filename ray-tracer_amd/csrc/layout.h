@@ -153,6 +153,7 @@ struct FrameArgs {
    int32_t n_dirs, n_materials;
    // tiles: this pass covers 8x8 pixel groups [micro_begin, micro_end) of the rank's enumeration
    int32_t tile_size, tile_rank, tile_world, tiles_x, tiles_y, micro_per_tile;
+   int32_t tile_compact;   // outputs in tile-compact order (settings.tile_compact)
    int32_t micro_begin, micro_end;
    uint32_t band_cap;   // slots per band sub-queue: ceil(groups in pass / N_BANDS) * 64 * multi_samples
    // scratch

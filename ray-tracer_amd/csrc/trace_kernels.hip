@@ -259,16 +259,20 @@ __device__ __forceinline__ void store_ray(float *rays, unsigned idx, V3 o, V3 d,
    q[1] = make_float4(d.x, d.y, d.z, __int_as_float(aux));
 }
 
-// pixel of (micro-tile, lane); false when it falls off the image
-__device__ __forceinline__ bool micro_pixel(const FrameArgs &p, int micro, int lane, int &px, int &py)
+// pixel of (micro-tile, lane); false when it falls off the image.  opix = where the pixel's outputs go: its place in the
+// image (y * width + x), or, with settings.tile_compact, in this rank's run of owned tiles (owned tile k, row-major
+// inside the tile): what the one exchange step of a multi-GPU frame sends as it is.
+__device__ __forceinline__ bool micro_pixel(const FrameArgs &p, int micro, int lane, int &px, int &py, long long &opix)
 {
    const int k = micro / p.micro_per_tile;
    const int within = micro % p.micro_per_tile;
    const int tile = p.tile_rank + k * p.tile_world;
    const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
    const int mpr = p.tile_size / 8;
-   px = tx * p.tile_size + (within % mpr) * 8 + (lane & 7);
-   py = ty * p.tile_size + (within / mpr) * 8 + (lane >> 3);
+   const int lx = (within % mpr) * 8 + (lane & 7), ly = (within / mpr) * 8 + (lane >> 3);
+   px = tx * p.tile_size + lx;
+   py = ty * p.tile_size + ly;
+   opix = p.tile_compact ? ((long long) k * p.tile_size + ly) * p.tile_size + lx : (long long) py * p.width + px;
    return (px < p.width) && (py < p.height);
 }
 
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
    const bool wave_ok = unit < per_band && local_micro < n_micro;
    const unsigned slot = ((unsigned) local_micro * (unsigned) ms + (unsigned) j) * 64u + (unsigned) lane;
    int px, py;
-   const bool active = micro_pixel(p, p.micro_begin + (wave_ok ? local_micro : 0), lane, px, py) && wave_ok;
+   long long opix;
+   const bool active = micro_pixel(p, p.micro_begin + (wave_ok ? local_micro : 0), lane, px, py, opix) && wave_ok;
    const long long pix = (long long) py * p.width + px;
 
    // RenderThread.java:39-47
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
    const bool push = active && any_root;
    if (active && !any_root) {
       ((float4 *) p.samples)[slot] = make_float4(p.light_ambient[0], p.light_ambient[1], p.light_ambient[2], 0.0f);
-      if (j == 0) write_miss_outputs(p, pix);
+      if (j == 0) write_miss_outputs(p, opix);
    }
    // the pass's 8x8 groups are cut into 8 bands (image order); each band has its own sub-queue
    const unsigned idx = (unsigned) band * p.band_cap + block_queue_push<GEN_WAVES>(p.counters + CNT_Q0 + band, push, s_cnt);
@@ -1163,8 +1168,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
          const int j = (int) (wave % (unsigned) p.multi_samples);
          if (j == 0 && (p.hit_id || p.hit_obj || p.hit_w)) {
             int px, py;
-            (void) micro_pixel(p, p.micro_begin + (int) (wave / (unsigned) p.multi_samples), (int) (slot & 63u), px, py);
-            const long long pix = (long long) py * p.width + px;
+            long long pix;
+            (void) micro_pixel(p, p.micro_begin + (int) (wave / (unsigned) p.multi_samples), (int) (slot & 63u), px, py, pix);
             if (obj < 0) {
                write_miss_outputs(p, pix);
             } else {
@@ -1244,8 +1249,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) void resolve_kernel(const FrameArgs 
    const long long local_micro = (long long) blockIdx.x * (BLOCK_THREADS / 64) + (threadIdx.x >> 6);
    if (local_micro >= (long long) (p.micro_end - p.micro_begin)) return;
    int px, py;
-   if (!micro_pixel(p, p.micro_begin + (int) local_micro, lane, px, py)) return;
-   const long long pix = (long long) py * p.width + px;
+   long long pix;
+   if (!micro_pixel(p, p.micro_begin + (int) local_micro, lane, px, py, pix)) return;
    const int ms = p.multi_samples;
    const float4 *s = (const float4 *) p.samples + (size_t) local_micro * (size_t) ms * 64 + lane;
    float r = 0.0f, g = 0.0f, b = 0.0f;
@@ -1341,6 +1346,46 @@ __global__ __launch_bounds__(BLOCK_THREADS) void image_pack_kernel(const float *
       c[2] = out[2];
    }
    argb[i] = pack_color(c[0], c[1], c[2]);
+}
+
+// ---------------------------------------------------------------- multi-GPU: tile-compact frames back into image order
+// One thread per (rank, owned-tile slot, pixel of the tile).  Every rank's block has the same layout:
+// [rgb: 3 n][hit_id: n][hit_obj: n][hit_w: n] words with n = slots_per_rank * tile^2 (mi355rt_tiles_unpack_device).
+__global__ __launch_bounds__(BLOCK_THREADS) void tiles_unpack_kernel(const float *all, int world, int slots_per_rank, int tile, int width, int height,
+                                                                     float *rgb, int32_t *hit_id, int32_t *hit_obj, float *hit_w)
+{
+   const long long tt = (long long) tile * tile;
+   const long long n = (long long) slots_per_rank * tt;
+   const long long i = (long long) blockIdx.x * BLOCK_THREADS + threadIdx.x;
+   if (i >= n * world) return;
+   const int r = (int) (i / n);
+   const long long e = i % n;
+   const int k = (int) (e / tt), within = (int) (e % tt);
+   const int tiles_x = (width + tile - 1) / tile, tiles_y = (height + tile - 1) / tile;
+   const long long t = (long long) r + (long long) k * world;
+   if (t >= (long long) tiles_x * tiles_y) return;
+   const int px = (int) (t % tiles_x) * tile + within % tile, py = (int) (t / tiles_x) * tile + within / tile;
+   if (px >= width || py >= height) return;
+   const float *blk = all + (size_t) r * 6 * (size_t) n;
+   const long long pix = (long long) py * width + px;
+   if (rgb) {
+      rgb[3 * pix + 0] = blk[3 * e + 0];
+      rgb[3 * pix + 1] = blk[3 * e + 1];
+      rgb[3 * pix + 2] = blk[3 * e + 2];
+   }
+   if (hit_id) hit_id[pix] = __float_as_int(blk[3 * n + e]);
+   if (hit_obj) hit_obj[pix] = __float_as_int(blk[4 * n + e]);
+   if (hit_w) hit_w[pix] = blk[5 * n + e];
+}
+
+hipError_t launch_tiles_unpack(const float *all, int world, int slots_per_rank, int tile, int width, int height, float *rgb, int32_t *hit_id,
+                               int32_t *hit_obj, float *hit_w, hipStream_t stream)
+{
+   const unsigned long long n = (unsigned long long) slots_per_rank * tile * tile * (unsigned long long) world;
+   if (!n) return hipSuccess;
+   hipLaunchKernelGGL(tiles_unpack_kernel, dim3((unsigned) ((n + BLOCK_THREADS - 1) / BLOCK_THREADS)), dim3(BLOCK_THREADS), 0, stream, all, world,
+                      slots_per_rank, tile, width, height, rgb, hit_id, hit_obj, hit_w);
+   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- ray batches (mi355rt_trace_rays)

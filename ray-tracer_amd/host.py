@@ -407,7 +407,7 @@ class Camera:
         self.hit_w = None
         self.lightingModel.setCamera(self)
 
-    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False, collect_times=False, collect_diag=False):
+    def settings(self, tile_rank=0, tile_world=1, tile_size=0, collect_stats=False, collect_times=False, collect_diag=False, tile_compact=False):
         st = _abi.Settings()
         st.epsilon = RTStatics.EPSILON
         st.near_plane = RTStatics.NEAR_PLANE
@@ -424,6 +424,7 @@ class Camera:
         st.tile_size = tile_size
         st.tile_rank = tile_rank
         st.tile_world = tile_world
+        st.tile_compact = 1 if tile_compact else 0
         st.collect_stats = (_abi.COLLECT_COUNTS if collect_stats else 0) | (_abi.COLLECT_TIMES if collect_times else 0) | \
             (_abi.COLLECT_DIAG if collect_diag else 0)
         return st

@@ -3,17 +3,25 @@
 The reference scatters pixels over `availableProcessors()` threads (Camera.java:129-143); samples
 are independent given the read-only scene.  Here the frame is cut into square tiles; tile t belongs
 to rank t % world (interleaved, because a statue sits mid-frame and bands would be imbalanced); the
-scene is replicated on every GPU.  Each rank renders its tiles into a full-size device frame
-(libmi355rt writes only owned tiles), packs them into one compact [tiles, T*T, 5] f32 tensor
-(r, g, b, w, id-bits) and the ONE exchange step is a gather of those tensors to rank 0, which
-scatters them back into frame order.  torch.distributed is plumbing: backend "nccl" (RCCL over xGMI)
-on GPUs, "gloo" in the CPU tests.
+scene is replicated on every GPU.
+
+Each rank renders its tiles straight into ONE compact block (settings.tile_compact: the library's
+resolve / shade / generate kernels write pixel (x, y) of the rank's k-th owned tile at element
+k*T*T + (y%T)*T + (x%T) of four planes [rgb: 3n][hit_id: n][hit_obj: n][hit_w: n], n = slots*T*T),
+so there is nothing to pack; the ONE exchange step is a gather of those blocks to rank 0, and one
+library kernel there (mi355rt_tiles_unpack_device) scatters all of them back into image order.
+torch.distributed is plumbing: backend "nccl" (RCCL over xGMI) on GPUs, "gloo" in the CPU tests,
+where the same layout is unpacked with index tensors (tiles_unpack_reference).
 """
+import ctypes as C
+
 import torch
 import torch.distributed as dist
 
+from . import _abi
+
 DEFAULT_TILE = 16
-CHANNELS = 5   # r, g, b, hit_w, hit_id (bit pattern)
+PLANES = 6   # words per pixel of a block: r, g, b, hit_id, hit_obj, hit_w
 
 
 def tile_grid(width, height, tile=DEFAULT_TILE):
@@ -45,67 +53,98 @@ def tile_pixels(width, height, tiles, tile=DEFAULT_TILE, device="cpu"):
     return idx.reshape(tiles.numel(), tile * tile)
 
 
-def pack_tiles(rgb, hit_w, hit_id, pix, n_slots):
-    """Gathers this rank's tiles out of its full-size frame into [n_slots, T*T, CHANNELS] (zero padded)."""
-    n, tt = pix.shape
-    out = torch.zeros((n_slots, tt, CHANNELS), dtype=torch.float32, device=rgb.device)
-    safe = pix.clamp(min=0).reshape(-1)
-    out[:n, :, 0:3] = rgb.reshape(-1, 3)[safe].reshape(n, tt, 3)
-    out[:n, :, 3] = hit_w.reshape(-1)[safe].reshape(n, tt)
-    out[:n, :, 4] = hit_id.reshape(-1)[safe].view(torch.float32).reshape(n, tt)
-    return out
+class Block:
+    """One rank's compact block: a flat f32 tensor of PLANES*n words and views of its four planes."""
+
+    def __init__(self, flat, n):
+        self.flat, self.n = flat, n
+        self.rgb = flat[: 3 * n].view(n, 3)
+        self.hit_id = flat[3 * n: 4 * n].view(torch.int32)
+        self.hit_obj = flat[4 * n: 5 * n].view(torch.int32)
+        self.hit_w = flat[5 * n: 6 * n]
+
+    def frame(self):
+        """_abi.Frame of device pointers into the block (what Camera.render_device(..., tile_compact=True) writes)."""
+        return _abi.Frame(self.rgb.data_ptr(), None, self.hit_id.data_ptr(), self.hit_obj.data_ptr(), self.hit_w.data_ptr())
 
 
-def unpack_tiles(packed, pix, rgb, hit_w, hit_id):
-    """Scatters one rank's packed tiles into the full frame tensors (in place)."""
-    n, _ = pix.shape
-    valid = pix.reshape(-1) >= 0
-    dst = pix.reshape(-1)[valid]
-    src = packed[:n].reshape(-1, CHANNELS)[valid]
-    rgb.reshape(-1, 3)[dst] = src[:, 0:3]
-    hit_w.reshape(-1)[dst] = src[:, 3]
-    hit_id.reshape(-1)[dst] = src[:, 4].contiguous().view(torch.int32)
+def tiles_pack_reference(rgb, hit_id, hit_obj, hit_w, rank, world, tile, block):
+    """What the library's kernels write with tile_compact, restated with index tensors (CPU tests): this rank's tiles
+    of full-size frame tensors -> its block."""
+    H, W = hit_id.shape
+    pix = tile_pixels(W, H, owned_tiles(W, H, rank, world, tile), tile, rgb.device)
+    n_own, tt = pix.shape
+    ok = (pix >= 0).reshape(-1)
+    src = pix.reshape(-1)[ok]
+    dst = torch.arange(n_own * tt, device=rgb.device)[ok]
+    block.rgb[dst] = rgb.reshape(-1, 3)[src]
+    block.hit_id[dst] = hit_id.reshape(-1)[src]
+    block.hit_obj[dst] = hit_obj.reshape(-1)[src]
+    block.hit_w[dst] = hit_w.reshape(-1)[src]
+
+
+def tiles_unpack_reference(blocks, world, slots, tile, rgb, hit_id, hit_obj, hit_w):
+    """mi355rt_tiles_unpack_device restated with index tensors (CPU tests): `world` consecutive blocks -> image order."""
+    H, W = hit_id.shape
+    n = slots * tile * tile
+    for r in range(world):
+        b = Block(blocks[r * PLANES * n: (r + 1) * PLANES * n], n)
+        pix = tile_pixels(W, H, owned_tiles(W, H, r, world, tile), tile, rgb.device)
+        ok = (pix >= 0).reshape(-1)
+        dst = pix.reshape(-1)[ok]
+        src = torch.arange(pix.numel(), device=rgb.device)[ok]
+        rgb.reshape(-1, 3)[dst] = b.rgb[src]
+        hit_id.reshape(-1)[dst] = b.hit_id[src]
+        hit_obj.reshape(-1)[dst] = b.hit_obj[src]
+        hit_w.reshape(-1)[dst] = b.hit_w[src]
 
 
 class TileSharder:
-    """Pre-computes every index tensor once; gather() is the per-frame exchange step and launches a fixed, small
-    number of kernels (no boolean masks, so no device-to-host synchronisation inside the timed step)."""
+    """The per-frame exchange of one rank.  `n_buffers` independent blocks let frames be in flight: frame k's block
+    travels while frame k + 1 renders into another."""
 
-    def __init__(self, width, height, rank, world, tile=DEFAULT_TILE, device="cpu"):
+    def __init__(self, width, height, rank, world, tile=DEFAULT_TILE, device="cpu", n_buffers=1):
         self.width, self.height, self.rank, self.world, self.tile = width, height, rank, world, tile
         self.device = torch.device(device)
-        self.n_slots = max_owned(width, height, world, tile)
-        tt = tile * tile
-        self.my_pix = tile_pixels(width, height, owned_tiles(width, height, rank, world, tile), tile, self.device)
-        self.n_mine = self.my_pix.shape[0]
-        self.my_safe = self.my_pix.clamp(min=0).reshape(-1)
-        self.send = torch.zeros((self.n_slots, tt, CHANNELS), dtype=torch.float32, device=self.device)
+        self.slots = max_owned(width, height, world, tile)
+        self.n = self.slots * tile * tile
+        self.blocks = [Block(torch.zeros(PLANES * self.n, dtype=torch.float32, device=self.device), self.n) for _ in range(n_buffers)]
+        self.recv = None
         if rank == 0 and world > 1:
-            self.recv_all = torch.empty((world, self.n_slots, tt, CHANNELS), dtype=torch.float32, device=self.device)
-            self.recv = [self.recv_all[r] for r in range(world)]
-            src, dst = [], []
-            for r in range(1, world):   # rank 0's own tiles are already in place
-                pix = tile_pixels(width, height, owned_tiles(width, height, r, world, tile), tile, self.device).reshape(-1)
-                keep = torch.nonzero(pix >= 0).squeeze(1)
-                src.append(keep + r * self.n_slots * tt)
-                dst.append(pix[keep])
-            self.src = torch.cat(src)
-            self.dst = torch.cat(dst)
+            self.recv = [torch.empty(world * PLANES * self.n, dtype=torch.float32, device=self.device) for _ in range(n_buffers)]
+        self._lib = _abi.load() if self.device.type == "cuda" else None
 
-    def gather(self, rgb, hit_w, hit_id):
-        """rgb [H,W,3] f32, hit_w [H,W] f32, hit_id [H,W] i32: this rank's frame (owned tiles valid).
-        On return rank 0's tensors hold the whole frame."""
+    def gather(self, rgb, hit_id, hit_obj, hit_w, buffer=0, async_op=False):
+        """Sends this rank's block `buffer` to rank 0 and, there, scatters all ranks' blocks into the frame tensors
+        (rgb [H,W,3] f32, hit_id / hit_obj [H,W] i32, hit_w [H,W] f32; any may be None on the GPU).  world == 1: the
+        frame was rendered in image order already, nothing to do.  async_op: returns a function that finishes the
+        exchange (waits for the gather, then unpacks on rank 0) -- call it after queueing the next frame."""
         if self.world == 1:
-            return
-        n, tt = self.n_mine, self.tile * self.tile
-        self.send[:n, :, 0:3] = rgb.reshape(-1, 3).index_select(0, self.my_safe).reshape(n, tt, 3)
-        self.send[:n, :, 3] = hit_w.reshape(-1).index_select(0, self.my_safe).reshape(n, tt)
-        self.send[:n, :, 4] = hit_id.reshape(-1).index_select(0, self.my_safe).view(torch.float32).reshape(n, tt)
+            return (lambda: None) if async_op else None
+        send = self.blocks[buffer].flat
         if self.rank == 0:
-            dist.gather(self.send, gather_list=self.recv, dst=0)
-            got = self.recv_all.reshape(-1, CHANNELS).index_select(0, self.src)
-            rgb.reshape(-1, 3).index_copy_(0, self.dst, got[:, 0:3])
-            hit_w.reshape(-1).index_copy_(0, self.dst, got[:, 3])
-            hit_id.reshape(-1).index_copy_(0, self.dst, got[:, 4].contiguous().view(torch.int32))
+            recv = self.recv[buffer]
+            work = dist.gather(send, gather_list=list(recv.view(self.world, -1).unbind(0)), dst=0, async_op=True)
         else:
-            dist.gather(self.send, gather_list=None, dst=0)
+            work = dist.gather(send, gather_list=None, dst=0, async_op=True)
+
+        def finish():
+            work.wait()   # on the GPU: the current stream waits for the collective; the host does not
+            if self.rank == 0:
+                self.unpack(self.recv[buffer], rgb, hit_id, hit_obj, hit_w)
+
+        if async_op:
+            return finish
+        finish()
+        return None
+
+    def unpack(self, blocks, rgb, hit_id, hit_obj, hit_w):
+        if self.device.type == "cuda":
+            fr = _abi.Frame(rgb.data_ptr() if rgb is not None else None, None, hit_id.data_ptr() if hit_id is not None else None,
+                            hit_obj.data_ptr() if hit_obj is not None else None, hit_w.data_ptr() if hit_w is not None else None)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            with torch.cuda.device(self.device):
+                _abi.check(self._lib.mi355rt_tiles_unpack_device(C.c_void_p(blocks.data_ptr()), self.world, self.slots, self.tile, self.width,
+                                                                 self.height, C.byref(fr), C.c_void_p(stream) if stream else None))
+        else:
+            tiles_unpack_reference(blocks, self.world, self.slots, self.tile, rgb, hit_id, hit_obj, hit_w)

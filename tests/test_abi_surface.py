@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(rt):
 
 
 def test_abi_version(rt):
-    assert rt._abi.load().mi355rt_abi_version() == 5
+    assert rt._abi.load().mi355rt_abi_version() == 6
 
 
 def test_struct_sizes_match_the_header(rt):
@@ -40,7 +40,8 @@ def test_struct_sizes_match_the_header(rt):
     assert C.sizeof(a.Material) == 4 + 12 * 4 + 4 + 4
     assert C.sizeof(a.BuildOpts) == 16
     assert C.sizeof(a.CameraDesc) == (3 + 9 + 3) * 4 + 8
-    assert C.sizeof(a.Settings) == 8 * 4 + 8 + 9 * 4 + 4 * 4 + 4  # padded to 8
+    assert C.sizeof(a.Settings) == 96 and a.Settings.tile_compact.offset == 92 and a.Settings.rng_seed.offset == 32
+    assert C.sizeof(a.MeshDesc) == 96 and a.MeshDesc.compute_kdtree.offset == 92
     assert C.sizeof(a.Stats) == 48
     assert C.sizeof(a.Frame) == 40
 

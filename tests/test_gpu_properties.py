@@ -77,6 +77,44 @@ def test_tile_shards_merge_to_the_whole_frame(rt):
     scene.close()
 
 
+def test_compact_blocks_unpack_to_the_whole_frame(rt):
+    """The multi-GPU data path on one GPU: every rank of an N-rank frame renders its tiles in tile-compact order into
+    its block (settings.tile_compact), the blocks laid end to end are what the gather delivers, and
+    mi355rt_tiles_unpack_device puts them back in image order -- equal to the single-rank frame bit for bit (ids,
+    objects, w, radiance), and equal to the index-tensor restatement the CPU (gloo) tests use.  Mesh over a mirror
+    floor, so hit objects differ; image sizes that are no multiple of the tile."""
+    import torch
+    from ray_tracer_amd import tiles
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+    v, i = rt.meshgen.stanford_standin("dragon", 20000)
+    blob = rt.TriangleMesh((v, i), rt.ColorInformation((0.9, 0.6, 0.3)), True)
+    fv, fi = rt.meshgen.quad(float(v[:, 1].min()) - 0.005, 0.3)
+    floor = rt.TriangleMesh((fv, fi), rt.ReflectionMaterial((0.8, 0.8, 0.8)), True)
+    scene = rt.Scene([blob, floor], light, (0, -25, 0), rt.PhongLightingModel(light, [blob, floor]), 23.0)
+    dev = torch.device("cuda", 0)
+    for (W, H, world, tile, spp) in ((203, 121, 3, 16, 2), (96, 70, 8, 8, 1), (333, 200, 2, 32, 1)):
+        cam = rt.Camera(scene, spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=9)
+        whole = [torch.full((H, W, 3), -1.0, device=dev), torch.full((H, W), -5, dtype=torch.int32, device=dev),
+                 torch.full((H, W), -5, dtype=torch.int32, device=dev), torch.full((H, W), -1.0, device=dev)]
+        cam.render_device(rt._abi.Frame(whole[0].data_ptr(), None, whole[1].data_ptr(), whole[2].data_ptr(), whole[3].data_ptr()))
+        sharders = [tiles.TileSharder(W, H, r, world, tile, dev) for r in range(world)]
+        for r, sh in enumerate(sharders):
+            cam.render_device(sh.blocks[0].frame(), tile_rank=r, tile_world=world, tile_size=tile, tile_compact=True)
+        torch.cuda.synchronize()
+        blocks = torch.cat([sh.blocks[0].flat for sh in sharders])
+        got = [torch.full_like(t, -9) for t in whole]
+        sharders[0].unpack(blocks, *got)
+        torch.cuda.synchronize()
+        for a, b in zip(whole, got):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (W, H, world, tile)
+        ref = [torch.full_like(t, -9).cpu() for t in whole]
+        tiles.tiles_unpack_reference(blocks.cpu(), world, sharders[0].slots, tile, *ref)
+        for a, b in zip(whole, ref):
+            assert torch.equal(a.cpu().view(torch.int32), b.view(torch.int32))
+        assert int((whole[2] == 1).sum()) > 0 and int((whole[2] == 0).sum()) > 0
+    scene.close()
+
+
 def test_multi_pass_frame(rt, orc):
     """A frame of more than 2^24 sample slots runs as several passes of the pipeline (api.cpp PASS_SLOTS)."""
     from helpers import compare_frames

@@ -123,16 +123,21 @@ def test_tile_bookkeeping():
             seen[valid] += 1
             assert pix.shape[0] <= tiles.max_owned(W, H, world, T)
         assert bool((seen == 1).all())                                    # every pixel owned exactly once
-    # pack / unpack round trip
+    # the compact block layout (what the library writes with settings.tile_compact) and back: every rank's tiles of
+    # one frame -> blocks -> image order
     rgb = torch.rand(H, W, 3)
     w = torch.rand(H, W)
     ids = torch.randint(-1, 1000, (H, W), dtype=torch.int32)
-    out = (torch.zeros_like(rgb), torch.zeros_like(w), torch.zeros_like(ids))
-    for r in range(3):
-        pix = tiles.tile_pixels(W, H, tiles.owned_tiles(W, H, r, 3, T), T)
-        packed = tiles.pack_tiles(rgb, w, ids, pix, tiles.max_owned(W, H, 3, T))
-        tiles.unpack_tiles(packed, pix, *out)
-    assert torch.equal(out[0], rgb) and torch.equal(out[1], w) and torch.equal(out[2], ids)
+    objs = torch.randint(-1, 5, (H, W), dtype=torch.int32)
+    for world in (1, 3, 4):
+        slots = tiles.max_owned(W, H, world, T)
+        n = slots * T * T
+        blocks = torch.full((world * tiles.PLANES * n,), -7.0)
+        for r in range(world):
+            tiles.tiles_pack_reference(rgb, ids, objs, w, r, world, T, tiles.Block(blocks[r * tiles.PLANES * n: (r + 1) * tiles.PLANES * n], n))
+        out = (torch.zeros_like(rgb), torch.zeros_like(ids), torch.zeros_like(objs), torch.zeros_like(w))
+        tiles.tiles_unpack_reference(blocks, world, slots, T, *out)
+        assert torch.equal(out[0], rgb) and torch.equal(out[1], ids) and torch.equal(out[2], objs) and torch.equal(out[3], w)
 
 
 def test_brdf_parse_rule(rt, tmp_path):

@@ -40,7 +40,7 @@ def _scenes(rt):
     fi = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
     floor = rt.TriangleMesh((fv, fi), rt.ReflectionMaterial((0.8, 0.8, 0.8)), True)
     blob2 = rt.TriangleMesh((v, i), rt.ColorInformation((0.9, 0.6, 0.3)), True)
-    mirror = rt.Scene([blob2, floor], light, (0, 20, 0), rt.PhongLightingModel(light, [blob2, floor]), 23.0)
+    mirror = rt.Scene([blob2, floor], light, (0, -20, 0), rt.PhongLightingModel(light, [blob2, floor]), 23.0)
     return [("plain", plain), ("mirror", mirror)]
 
 
@@ -61,7 +61,7 @@ def test_noalloc_frames_equal_render_device_frames(rt):
                 assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, W, H, spp, k)
             assert int((want[2] >= 0).sum()) > W * H // 20   # the frame shows the object
             if name == "mirror":
-                assert int((want[3] == 1).sum()) > 0          # and the mirror floor
+                assert int((want[3] == 1).sum()) > 0 and int((want[3] == 0).sum()) > 0   # the mirror floor and the mesh on it
         scene.close()
 
 
