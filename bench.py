@@ -65,6 +65,10 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--material", default="color", choices=["color", "brdf", "mirror-floor"],
+                    help="color: ColorInformation(0.9) as RayTracer.java:122-123; brdf: BRDFMaterial(15) on the reference's CUReT tables "
+                         "(configs[2]); mirror-floor: the mesh over a ReflectionMaterial floor (configs[3]: secondary rays)")
+    ap.add_argument("--brdf-samples", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the blocking_render and soup objects (profiling runs)")
     ap.add_argument("--emulate-world", type=int, default=0,
@@ -217,12 +221,22 @@ def main():
 
     cfg, verts, idx, normals, label = load_model(rt, args)
     light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))          # RayTracer.java:106
-    mesh = rt.TriangleMesh((verts, idx) if normals is None else (verts, idx, normals), rt.ColorInformation((0.9, 0.9, 0.9)), True)  # RayTracer.java:122-123
+    if args.material == "brdf":
+        from helpers import curet_tables   # tests/golden/curet_tables.npz: the reference's resources/table.txt + abrdf.dat, parsed
+        rt.BRDFMaterial.setTables(*curet_tables())
+        color = rt.BRDFMaterial(15, (0.0, 1.0, 0.0))               # RayTracer.java:162
+    else:
+        color = rt.ColorInformation((0.9, 0.9, 0.9))               # RayTracer.java:122-123
+    mesh = rt.TriangleMesh((verts, idx) if normals is None else (verts, idx, normals), color, True)
+    objects = [mesh]
+    if args.material == "mirror-floor":   # a lone mirrored mesh reflects nothing (ReflectionMaterial.java:14-24 skips the object itself)
+        fv, fi = rt.meshgen.quad(float(verts[:, 1].min()) - 0.01 * cfg["span"], 0.8 * cfg["span"])
+        objects.append(rt.TriangleMesh((fv, fi), rt.ReflectionMaterial((0.8, 0.8, 0.8)), True))
     t0 = time.time()
-    scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"], device=local_rank)
+    scene = rt.Scene(objects, light, cfg["orientation"], rt.PhongLightingModel(light, objects), cfg["fov"], device=local_rank)
     build_s = time.time() - t0
     W, H = args.width, args.height
-    cam = rt.Camera(scene, args.spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
+    cam = rt.Camera(scene, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
 
     rgb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     hit_id = torch.zeros((H, W), dtype=torch.int32, device=dev)
@@ -299,7 +313,7 @@ def main():
     # with the chip draining; the next frame's bulk fills that in.  All ranks take part (the gathers are collectives).
     pipelined = None
     if tile_world == world and args.frames_in_flight > 1:
-        pipelined = frames_in_flight(rt, tiles, args, mesh, light, cfg, dev, rank, world, W, H, rays_per_frame)
+        pipelined = frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, W, H, rays_per_frame)
 
     # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
     frame_verified = None
@@ -375,11 +389,11 @@ def main():
     blocking = soup = None
     if world == 1 and tile_world == 1 and not args.no_extras:
         blocking = blocking_render(rt, cam, rays_per_frame)
-        if args.model == "dragon" and not args.models_dir:
+        if args.model == "dragon" and not args.models_dir and args.material == "color":
             soup = soup_line(rt, args, light, cfg, dev, W, H)
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.material == "color":
         cpu = cpu_baseline(args, verts, idx, normals, cfg, light)
 
     out = {
@@ -388,8 +402,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if not args.models_dir else "PLY file",
-        "config": {"workload": "%s %dx%d, %d spp, Phong, primary+shadow" % (label, W, H, args.spp),
-                   "rays_per_frame": int(rays_per_frame), "primary": int(primary), "shadow": int(shadow),
+        "config": {"workload": "%s %dx%d, %d spp, Phong, primary+shadow%s" % (label, W, H, args.spp, {"color": "", "brdf": ", BRDFMaterial(15) on the CUReT tables, brdf_samples %d" % args.brdf_samples, "mirror-floor": ", over a ReflectionMaterial floor (secondary rays)"}[args.material]),
+                   "rays_per_frame": int(rays_per_frame), "primary": int(primary), "shadow": int(shadow), "secondary": int(secondary),
                    "tile": tiles.DEFAULT_TILE, "parallelism": "tiles%d" % world,
                    "hierarchy": {k: scene.object_info(0)[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")},
                    "scene_hbm_bytes": scene.device_bytes(), "scene_build_s": round(build_s, 2)},
@@ -423,13 +437,13 @@ def shadow_any_hit_proven(scene, light):
     return float(np.linalg.norm(d)) > 1.01 * diag
 
 
-def frames_in_flight(rt, tiles, args, mesh, light, cfg, dev, rank, world, W, H, rays_per_frame):
+def frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, W, H, rays_per_frame):
     """K frames with D in flight on every rank: D scene handles (each owns its scratch) on D streams, round robin, no host
     sync between; with N > 1 each frame's block is gathered asynchronously and unpacked on rank 0 when its buffer comes
     round again, so the exchange of frame k runs under the render of frame k + 1."""
     D = args.frames_in_flight
-    scenes = [rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"], device=dev.index) for _ in range(D)]
-    cams = [rt.Camera(s, args.spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024) for s in scenes]
+    scenes = [rt.Scene(objects, light, cfg["orientation"], rt.PhongLightingModel(light, objects), cfg["fov"], device=dev.index) for _ in range(D)]
+    cams = [rt.Camera(s, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024) for s in scenes]
     streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
     sh = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev, n_buffers=D)
     full = rank == 0

@@ -82,6 +82,14 @@ def synthetic_brdf_tables(n_dirs=205, n_materials=8, seed=7):
     return ang, w
 
 
+def curet_tables():
+    """The reference's own CUReT tables (resources/table.txt, resources/abrdf.dat) as committed, parsed, in
+    tests/golden/curet_tables.npz (tests/golden/make_curet_golden.py): angles[205, 4], weights[61, 205]."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "curet_tables.npz"))
+    return f["angles"], f["weights"]
+
+
 def compare_frames(g_rgb, g_id, g_w, o, rtol=1e-3, atol=1e-6, g_obj=None):
     """ids, hit objects and w bit-exact; radiance within 1e-3 relative (north_star), NaN-scrubbed pixels equal.
     g_obj: the frame's hit-object indices (a face index alone does not tell two objects' faces apart)."""

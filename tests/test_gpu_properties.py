@@ -320,6 +320,7 @@ def _compare_at_sampled_pixels(cam, o, rtol=1e-3):
     m = o["hit_id"] != -2
     assert m.sum() > 1000
     assert np.array_equal(cam.hit_id.T[m], o["hit_id"][m]), int((cam.hit_id.T[m] != o["hit_id"][m]).sum())
+    assert np.array_equal(cam.hit_obj.T[m], o["hit_obj"][m])
     assert np.array_equal(cam.hit_w.T[m].view(np.uint32), o["hit_w"][m].view(np.uint32))
     denom = np.maximum(np.abs(o["rgb"][m]), 1e-3)
     rel = np.abs(cam._rgb_rows[m] - o["rgb"][m]) / denom
@@ -329,20 +330,21 @@ def _compare_at_sampled_pixels(cam, o, rtol=1e-3):
 
 def test_buddha_config_brdf_full_size(rt, orc):
     """BASELINE configs[2]: Buddha-class mesh (1,087,716 faces), 1920x1080, measured-BRDF material under Phong,
-    orientation (180,0,0), fov 10 (RayTracer.java:125-128).  The whole frame on the GPU; the oracle (its table
-    search is slow on a CPU) checks every 7th pixel."""
-    from helpers import synthetic_brdf_tables
+    orientation (180,0,0), fov 10 (RayTracer.java:125-128) -- on the reference's own CUReT tables (abrdf.dat row 15, the
+    material RayTracer.java:162 uses; tests/golden/curet_tables.npz).  The whole frame on the GPU; the oracle (its
+    table search is slow on a CPU) checks every 7th pixel."""
+    from helpers import curet_tables
     cfg = rt.meshgen.STANFORD["buddha"]
     v, i = rt.meshgen.stanford_standin("buddha")
     assert i.shape[0] == 1087716
-    tables = synthetic_brdf_tables()
+    tables = curet_tables()
     rt.BRDFMaterial.setTables(*tables)
     light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
-    mesh = rt.TriangleMesh((v, i), rt.BRDFMaterial(3, (0.2, 0.8, 0.3)), True)
+    mesh = rt.TriangleMesh((v, i), rt.BRDFMaterial(15, (0.0, 1.0, 0.0)), True)
     scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"])
     cam = rt.Camera(scene, 1, 2, rt.RTStatics.NEAR_PLANE, 1920, 1080, rng_seed=5)
     cam.createImage()
-    osc = orc.OracleScene([(v, i, None, orc.material(kind=1, diffuse=(0.2, 0.8, 0.3), brdf_id=3))])
+    osc = orc.OracleScene([(v, i, None, orc.material(kind=1, diffuse=(0.0, 1.0, 0.0), brdf_id=15))])
     osc.set_brdf(*tables)
     ocam = osc.camera(cfg["orientation"], cfg["fov"], rt.RTStatics.NEAR_PLANE, 1920, 1080)
     ost = orc.settings(epsilon=osc.epsilon(), ms=1, brdf_samples=2, lighting=1, seed=5, light_origin=light.origin,
@@ -369,4 +371,83 @@ def test_thai_class_mirror_4k_two_passes(rt, orc):
     o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=211, want_stats=True)
     frac = _compare_at_sampled_pixels(cam, o)
     assert frac > 0.2 and o["stats"]["secondary_rays"] > 10000
+    pair.close()
+
+
+def test_lucy_class_parity_4k(rt, orc):
+    """BASELINE configs[4] at a size the oracle can follow: the Lucy stand-in at 3,000,000 faces -- span 1500 (EPSILON =
+    1e-3, Scene.java:36), orientation (0,-90,0), fov 10, light (0,100,100) INSIDE the scene's box (RayTracer.java:106,129-132),
+    so the shadow rays run RTStatics.shadowIntersects' own closest-hit rule (MODE_SHADOW) -- at 3840x2160, 2 spp.  The
+    hierarchy hits the reference's depth limit of 20 (leaves of many faces), where the walker changes character.  The
+    oracle checks every 199th pixel: faces, objects, w bit-exact, radiance within 1e-3."""
+    from helpers import Pair
+    cfg = rt.meshgen.STANFORD["lucy"]
+    v, i = rt.meshgen.stanford_standin("lucy", 3000000)
+    pair = Pair([(v, i, None, rt.ColorInformation((1.0, 1.0, 1.0)))], orientation=cfg["orientation"], fov=cfg["fov"])
+    assert np.float32(pair.eps) == np.float32(1e-3)
+    info = pair.scene.object_info(0)
+    assert info["max_depth"] == 20 and info["n_leaf_slots"] > 5 * info["n_leaves"]      # depth-capped leaves
+    cam, ocam, ost = pair.cameras(3840, 2160, ms=2, seed=31)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=199, want_stats=True)
+    frac = _compare_at_sampled_pixels(cam, o)
+    assert frac > 0.05 and o["stats"]["shadow_rays"] > 1000
+    # some sampled pixels are in shadow and some are lit: both outcomes of the exact rule occur
+    m = o["hit_id"] >= 0
+    lum = o["rgb"][m].sum(axis=1)
+    assert lum.min() < 0.7 * lum.max()
+    pair.close()
+
+
+def test_lucy_config_full_size_properties(rt):
+    """BASELINE configs[4] at full size -- 28,055,742 faces, 3840x2160, 16 spp (8 passes), Phong, exact shadows -- through
+    properties that need no oracle: every sample is a primary ray, every hit sample casts one shadow ray, two renders are
+    bit-identical (whatever wave walked or stole what), and the first sample's hits agree with a 1-spp frame's."""
+    import torch
+    cfg = rt.meshgen.STANFORD["lucy"]
+    v, i = rt.meshgen.stanford_standin("lucy")
+    assert i.shape[0] == 28055742
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+    mesh = rt.TriangleMesh((v, i), rt.ColorInformation((1.0, 1.0, 1.0)), True)
+    scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"])
+    del v, i
+    W, H, spp = 3840, 2160, 16
+    cam = rt.Camera(scene, spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
+    fa, rgba, ida, wa = _device_frame(rt, cam)
+    fb, rgbb, idb, wb = _device_frame(rt, cam)
+    cam.render_device(fa, collect_stats=True)
+    torch.cuda.synchronize()
+    st = cam.frame_stats()
+    assert st["primary_rays"] == W * H * spp
+    assert st["shadow_rays"] == st["hits"] > W * H * spp // 50
+    cam.render_device(fb)
+    torch.cuda.synchronize()
+    assert torch.equal(ida, idb) and torch.equal(wa, wb) and torch.equal(rgba.view(torch.int32), rgbb.view(torch.int32))
+    cam1 = rt.Camera(scene, 1, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)     # sample 0 is unjittered: same rays
+    cam1.render_device(fb)
+    torch.cuda.synchronize()
+    assert torch.equal(ida, idb) and torch.equal(wa, wb)
+    assert bool(torch.isfinite(rgba).all())
+    scene.close()
+
+
+def test_thai_config_full_size_16spp(rt, orc):
+    """BASELINE configs[3] at full size: the Thai-statuette stand-in, 10,000,000 faces of span 400 (EPSILON = 1e-3) with
+    ReflectionMaterial over a floor (a lone mirrored mesh reflects nothing: ReflectionMaterial.java:14-24 skips the object
+    itself), orientation (0,0,0) tilted to show the floor, 3840x2160 at 16 spp = 132.7 M samples in 8 passes with mirror
+    bounces.  The oracle checks every 499th pixel (all 16 samples, shadow and bounce rays of each)."""
+    from helpers import Pair
+    cfg = rt.meshgen.STANFORD["thai"]
+    v, i = rt.meshgen.stanford_standin("thai")
+    assert i.shape[0] == 10000000
+    fv, fi = rt.meshgen.quad(float(v[:, 1].min()) - 5.0, 230.0)
+    pair = Pair([(v, i, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))), (fv, fi, None, rt.ColorInformation((0.8, 0.3, 0.2)))],
+                orientation=(0, -20, 0), fov=30.0)
+    assert np.float32(pair.eps) == np.float32(1e-3)
+    cam, ocam, ost = pair.cameras(3840, 2160, ms=16, seed=23)
+    cam.createImage()
+    o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=499, want_stats=True)
+    frac = _compare_at_sampled_pixels(cam, o)
+    assert frac > 0.2 and o["stats"]["secondary_rays"] > 10000
+    assert o["stats"]["primary_rays"] == 16 * int((o["hit_id"] != -2).sum())
     pair.close()

@@ -6,14 +6,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 import ray_tracer_amd as rt
-from helpers import synthetic_brdf_tables
+from helpers import curet_tables
 
 brdf_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cfg = rt.meshgen.STANFORD["buddha"]
 v, i = rt.meshgen.stanford_standin("buddha")
-rt.BRDFMaterial.setTables(*synthetic_brdf_tables())
+rt.BRDFMaterial.setTables(*curet_tables())   # the reference's own tables (tests/golden/curet_tables.npz)
 light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
-mesh = rt.TriangleMesh((v, i), rt.BRDFMaterial(3, (0.2, 0.8, 0.3)), True)
+mesh = rt.TriangleMesh((v, i), rt.BRDFMaterial(15, (0.0, 1.0, 0.0)), True)
 scene = rt.Scene([mesh], light, cfg["orientation"], rt.PhongLightingModel(light, [mesh]), cfg["fov"])
 for ms in (1, 4):
     cam = rt.Camera(scene, ms, brdf_samples, rt.RTStatics.NEAR_PLANE, 1920, 1080, rng_seed=5)
