@@ -1121,6 +1121,39 @@ int orc_trace_rays(const orc_scene *s, const orc_settings *st, uint64_t n, const
    return 0;
 }
 
+/* closest hit of each ray, then camera.lightingModel.getPixelColor(info, 0) for it (RenderThread.java:49-52 for an
+ * arbitrary ray): what tools/java/GoldenDumper.java prints from the reference itself */
+int orc_shade_rays(const orc_scene *s, const orc_settings *st, uint64_t n, const float *origins, const float *dirs,
+                   int32_t *hit_obj, float *hit_w, float *hit_point, float *hit_normal, float *rgb)
+{
+   ctx c;
+   uint64_t i;
+   if (!s || !st || !hit_obj || !hit_w || !hit_point || !hit_normal || !rgb) return -1;
+   memset(&c, 0, sizeof(c));
+   c.scene = s;
+   c.st = st;
+   for (i = 0; i < n; i++) {
+      v3 o = { origins[3 * i], origins[3 * i + 1], origins[3 * i + 2] };
+      v3 d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
+      hitinfo h;
+      float col[3] = { 0.0f, 0.0f, 0.0f };
+      if (closest_intersection(&c, -1, o, d, NULL, &h)) {
+         pixel_color(&c, &h, col);
+         hit_obj[i] = h.obj;
+         hit_w[i] = h.w;
+         hit_point[3 * i] = h.point.x; hit_point[3 * i + 1] = h.point.y; hit_point[3 * i + 2] = h.point.z;
+         hit_normal[3 * i] = h.normal.x; hit_normal[3 * i + 1] = h.normal.y; hit_normal[3 * i + 2] = h.normal.z;
+      } else {
+         hit_obj[i] = -1;
+         hit_w[i] = 0.0f;
+         hit_point[3 * i] = hit_point[3 * i + 1] = hit_point[3 * i + 2] = 0.0f;
+         hit_normal[3 * i] = hit_normal[3 * i + 1] = hit_normal[3 * i + 2] = 0.0f;
+      }
+      rgb[3 * i] = col[0]; rgb[3 * i + 1] = col[1]; rgb[3 * i + 2] = col[2];
+   }
+   return 0;
+}
+
 /* ---------------------------------------------------------------- scene create / camera */
 
 int orc_scene_create_objects(const orc_object_desc *objects, uint32_t n_objects, const orc_build_opts *opts, orc_scene **out)

@@ -126,6 +126,10 @@ int orc_trace_rays(const orc_scene *s, const orc_settings *st, uint64_t n, const
                    const float *dirs, int32_t *hit_id, int32_t *hit_obj, float *hit_w,
                    float *hit_point, float *hit_normal);
 
+/* the same, followed by lightingModel.getPixelColor(info, 0) of each hit (all outputs required); see tools/java/GoldenDumper.java */
+int orc_shade_rays(const orc_scene *s, const orc_settings *st, uint64_t n, const float *origins, const float *dirs,
+                   int32_t *hit_obj, float *hit_w, float *hit_point, float *hit_normal, float *rgb);
+
 /* unit pieces for known-answer tests */
 int orc_aabb_intersection(const float o[3], const float d[3], const float minmax[6], float near_plane, float far_plane);
 int orc_intersects_triangle(const float o[3], const float d[3], const float p[9], const float n[9], float eps, float out[7]);

@@ -94,6 +94,7 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.c_int32, C.c_int32, fp, ip, ip, fp,
                                  C.POINTER(Stats)]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_uint64, fp, fp, ip, ip, fp, fp, fp]
+        L.orc_shade_rays.argtypes = [C.c_void_p, C.POINTER(Settings), C.c_uint64, fp, fp, ip, fp, fp, fp, fp]
         L.orc_aabb_intersection.argtypes = [fp, fp, fp, C.c_float, C.c_float]
         L.orc_intersects_triangle.argtypes = [fp, fp, fp, fp, C.c_float, fp]
         L.orc_reflection_direction.argtypes = [fp, fp, fp]
@@ -274,6 +275,16 @@ class OracleScene:
         hn = np.empty((n, 3), dtype=np.float32)
         assert lib().orc_trace_rays(self.h, C.byref(st), n, P(o), P(d), PI(hid), PI(hobj), P(hw), P(hp), P(hn)) == 0
         return {"face": hid, "object": hobj, "w": hw, "point": hp, "normal": hn}
+
+    def shade(self, st, origins, dirs):
+        """Closest hit and lightingModel.getPixelColor(info, 0) of each ray (orc_shade_rays)."""
+        o, d = f32(origins).reshape(-1, 3), f32(dirs).reshape(-1, 3)
+        n = o.shape[0]
+        hobj = np.empty(n, dtype=np.int32)
+        hw = np.empty(n, dtype=np.float32)
+        hp, hn, rgb = (np.empty((n, 3), dtype=np.float32) for _ in range(3))
+        assert lib().orc_shade_rays(self.h, C.byref(st), n, P(o), P(d), PI(hobj), P(hw), P(hp), P(hn), P(rgb)) == 0
+        return {"object": hobj, "w": hw, "point": hp, "normal": hn, "rgb": rgb}
 
     def close(self):
         if self.h:
