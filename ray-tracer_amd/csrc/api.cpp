@@ -159,8 +159,10 @@ struct mi355rt_scene {
    bool has_refraction = false;
    bool boxes_finite = true;        // see SceneArgs.boxes_finite
    bool any_gpu_build = false;
-   size_t n_node_recs = 0, n_tri_floats = 0, n_fnrm_floats = 0;   // sizes of d_nodes / d_tris / d_fnrm
-   void *d_nodes = nullptr, *d_tris = nullptr, *d_fnrm = nullptr;   // all objects, concatenated
+   size_t n_node_recs = 0, n_descs = 0, n_gface_floats = 0, n_slots = 0, n_fnrm_floats = 0;   // sizes of the arrays below
+   void *d_nodes = nullptr, *d_descs = nullptr, *d_gfaces = nullptr, *d_fnrm = nullptr;   // all objects, concatenated (layout.h)
+   int32_t *d_slot_ids = nullptr;
+   uint64_t n_groups = 0, n_shared_groups = 0;
    float *d_brdf_dirs = nullptr, *d_brdf_weights = nullptr;
    int32_t n_dirs = 0, n_materials = 0;
    float smin[3], smax[3];   // scene bounds (Scene.java:21-33)
@@ -207,7 +209,9 @@ void release_scene_impl(mi355rt_scene *s)
 {
    if (!s) return;
    if (s->d_nodes) (void) hipFree(s->d_nodes);
-   if (s->d_tris) (void) hipFree(s->d_tris);
+   if (s->d_descs) (void) hipFree(s->d_descs);
+   if (s->d_gfaces) (void) hipFree(s->d_gfaces);
+   if (s->d_slot_ids) (void) hipFree(s->d_slot_ids);
    if (s->d_fnrm) (void) hipFree(s->d_fnrm);
    if (s->d_objs) (void) hipFree(s->d_objs);
    if (s->d_ext) (void) hipFree(s->d_ext);
@@ -360,24 +364,23 @@ std::string add_analytic_object(mi355rt_scene *s, const mi355rt_object_desc &od,
    return std::string();
 }
 
-// One mesh's share of the scene's node and leaf-slot arrays: built on the host (scene_build.cpp) or on the GPU
-// (gpu_build.hip), copied to its place once every object's size is known.
+// One mesh's share of the scene's arrays, on the host: the hierarchy comes from the host builder (scene_build.cpp) or
+// from the GPU builder (gpu_build.hip, downloaded), its leaves are grouped (scene_build.hpp "leaf groups"), and every
+// part is copied to its place once all objects' sizes are known.
 struct ScenePart {
-   std::vector<DevNodeRec> nodes;   // host-built: records with absolute links
-   std::vector<float> tris;         // host-built: 12 floats per slot
-   GpuBuiltObject gpu;              // GPU-built: device buffers with relative links
-   bool on_gpu = false;
-   size_t node_base = 0, slot_base = 0, n_nodes = 0, n_slots = 0;
+   std::vector<DevNodeRec> nodes;    // links relative to the part: node index / index of a leaf's first descriptor
+   std::vector<int32_t> slot_face;   // face id per leaf slot, the reference's order
+   GroupedLeaves groups;             // descs (key / gbase relative to the part), group-face ids
+   bool on_gpu = false;              // built by gpu_build.hip
+   size_t node_base = 0, slot_base = 0, desc_base = 0, gface_base = 0;
+   int32_t root_link = 0, root_cnt = 0;
 };
 
-// The host builder's output as the uploaded records (layout.h): node records with both children interleaved and
-// absolute links, and one 48-byte slot per (leaf, face).
-void host_part_records(const BuiltObject &built, const mi355rt_mesh_desc &md, ScenePart &part, bool &boxes_finite)
+// the host builder's records in the uploaded form (both children interleaved per coordinate)
+void host_part_records(const BuiltObject &built, ScenePart &part)
 {
    part.nodes.reserve(built.nodes.size());
-   for (NodeRec rec : built.nodes) {
-      if (rec.llink != LINK_NONE) rec.llink += (int32_t) (rec.lcnt > 0 ? part.slot_base : part.node_base);
-      if (rec.rlink != LINK_NONE) rec.rlink += (int32_t) (rec.rcnt > 0 ? part.slot_base : part.node_base);
+   for (const NodeRec &rec : built.nodes) {
       DevNodeRec d;
       const float *lo[2] = { rec.lmin, rec.rmin }, *hi[2] = { rec.lmax, rec.rmax };
       for (int side = 0; side < 2; side++) {
@@ -387,33 +390,18 @@ void host_part_records(const BuiltObject &built, const mi355rt_mesh_desc &md, Sc
          d.hi_x[side] = hi[side][0];
          d.hi_y[side] = hi[side][1];
          d.hi_z[side] = hi[side][2];
-         for (int c = 0; c < 3; c++) boxes_finite = boxes_finite && std::isfinite(lo[side][c]) && std::isfinite(hi[side][c]);
       }
       d.llink = rec.llink;
       d.rlink = rec.rlink;
       d.lcnt = rec.lcnt;
       d.rcnt = rec.rcnt;
+      d.lgbase = d.rgbase = 0;
+      d.lmask = d.rmask = 0u;
       part.nodes.push_back(d);
    }
-   // leaf slots: { v0, faceId } { v1, faces left in the leaf } { v2, index of the slot in its leaf }
-   part.tris.assign(12 * built.slot_face.size(), 0.0f);
-   int32_t in_leaf = 0;
-   for (size_t sidx = 0; sidx < built.slot_face.size(); sidx++) {
-      const int32_t f = built.slot_face[sidx];
-      float *dst = part.tris.data() + 12 * sidx;
-      for (int kx = 0; kx < 3; kx++) {
-         const float *v = md.vertices + 3 * (size_t) md.indices[3 * (size_t) f + kx];
-         dst[4 * kx + 0] = v[0];
-         dst[4 * kx + 1] = v[1];
-         dst[4 * kx + 2] = v[2];
-         dst[4 * kx + 3] = 0.0f;
-      }
-      std::memcpy(&dst[3], &f, sizeof(float));
-      const int32_t remaining = built.slot_remaining[sidx];
-      std::memcpy(&dst[7], &remaining, sizeof(float));
-      in_leaf = (sidx == 0 || built.slot_remaining[sidx - 1] == 1) ? 0 : in_leaf + 1;   // a leaf ends on the slot with 1 face left
-      std::memcpy(&dst[11], &in_leaf, sizeof(float));
-   }
+   part.slot_face = built.slot_face;
+   part.root_link = built.root_link;
+   part.root_cnt = built.root_cnt;
 }
 
 // 48 bytes per face: the three vertex normals, fetched once per final hit
@@ -431,32 +419,66 @@ void append_face_normals(std::vector<float> &all_fnrm, size_t face_base, const m
    }
 }
 
-// Allocates the scene's node and leaf-slot arrays and copies every part to its place.  LEAF_PAD_SLOTS zero slots
-// (one face left) follow the last leaf: a walker reads a few slots past a leaf's end.
-hipError_t upload_parts(mi355rt_scene *s, std::vector<ScenePart> &parts, size_t node_total, size_t slot_total)
+// Groups the part's leaves, makes its links absolute and notes whether every box is finite.
+void finish_part(ScenePart &part, bool &boxes_finite)
+{
+   group_leaves(part.nodes.data(), part.nodes.size(), sizeof(DevNodeRec), part.slot_face.data(), part.root_link, part.root_cnt, part.groups);
+   for (DevNodeRec &d : part.nodes) {
+      // a leaf child's descriptor words ride in its parent's record (layout.h); the group base made absolute like the descriptor's own
+      d.lgbase = d.rgbase = 0;
+      d.lmask = d.rmask = 0u;
+      if (d.llink != LINK_NONE && d.lcnt > 0) {
+         d.lgbase = part.groups.descs[(size_t) d.llink].gbase + (int32_t) part.gface_base;
+         d.lmask = part.groups.descs[(size_t) d.llink].mask;
+      }
+      if (d.rlink != LINK_NONE && d.rcnt > 0) {
+         d.rgbase = part.groups.descs[(size_t) d.rlink].gbase + (int32_t) part.gface_base;
+         d.rmask = part.groups.descs[(size_t) d.rlink].mask;
+      }
+      if (d.llink != LINK_NONE) d.llink += (int32_t) (d.lcnt > 0 ? part.desc_base : part.node_base);
+      if (d.rlink != LINK_NONE) d.rlink += (int32_t) (d.rcnt > 0 ? part.desc_base : part.node_base);
+      for (int side = 0; side < 2; side++)
+         boxes_finite = boxes_finite && std::isfinite(d.lo_x[side]) && std::isfinite(d.lo_y[side]) && std::isfinite(d.lo_z[side]) &&
+                        std::isfinite(d.hi_x[side]) && std::isfinite(d.hi_y[side]) && std::isfinite(d.hi_z[side]);
+   }
+   for (LeafDesc &d : part.groups.descs) {
+      d.key += (int32_t) part.slot_base;
+      d.gbase += (int32_t) part.gface_base;   // the flag bits sit above DESC_BASE_MASK
+   }
+}
+
+// Allocates the scene's node, descriptor, group-face and slot-id arrays and fills each part's share.  GFACE_PAD zero
+// faces follow the last group: a lane that sits a trip out reads entry 0, a leaf's last odd face reads one entry on.
+hipError_t upload_parts(mi355rt_scene *s, const std::vector<ScenePart> &parts, const mi355rt_object_desc *objects, size_t node_total, size_t slot_total,
+                        size_t desc_total, size_t gface_total)
 {
    const size_t node_bytes = std::max<size_t>(node_total, 1) * sizeof(DevNodeRec);
-   const size_t tri_floats = 12 * (slot_total + LEAF_PAD_SLOTS);
+   const size_t desc_bytes = (desc_total + DESC_PAD) * sizeof(LeafDesc);
+   const size_t gface_floats = 12 * (gface_total + GFACE_PAD);
+   const size_t slot_bytes = std::max<size_t>(slot_total, 1) * sizeof(int32_t);
    hipError_t e = hipMalloc(&s->d_nodes, node_bytes);
-   if (e == hipSuccess) e = hipMalloc(&s->d_tris, tri_floats * sizeof(float));
+   if (e == hipSuccess) e = hipMalloc(&s->d_descs, desc_bytes);
+   if (e == hipSuccess) e = hipMalloc(&s->d_gfaces, gface_floats * sizeof(float));
+   if (e == hipSuccess) e = hipMalloc((void **) &s->d_slot_ids, slot_bytes);
    if (e != hipSuccess) return e;
-   s->device_bytes += node_bytes + tri_floats * sizeof(float);
+   s->device_bytes += node_bytes + desc_bytes + gface_floats * sizeof(float) + slot_bytes;
    s->n_node_recs = node_total;
-   s->n_tri_floats = tri_floats;
-   std::vector<float> pad(12 * (size_t) LEAF_PAD_SLOTS, 0.0f);
-   const int32_t one = 1;
-   for (int q = 0; q < LEAF_PAD_SLOTS; q++) std::memcpy(&pad[12 * (size_t) q + 7], &one, sizeof(float));
-   e = hipMemcpy((float *) s->d_tris + 12 * slot_total, pad.data(), pad.size() * sizeof(float), hipMemcpyHostToDevice);
-   for (ScenePart &part : parts) {
-      if (e != hipSuccess) break;
-      if (part.on_gpu) {
-         e = gpu_build_relocate(part.gpu, (DevNodeRec *) s->d_nodes, (float *) s->d_tris, (int32_t) part.node_base, (int32_t) part.slot_base);
-      } else {
-         if (!part.nodes.empty())
-            e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, part.nodes.data(), part.nodes.size() * sizeof(DevNodeRec), hipMemcpyHostToDevice);
-         if (e == hipSuccess && !part.tris.empty())
-            e = hipMemcpy((float *) s->d_tris + 12 * part.slot_base, part.tris.data(), part.tris.size() * sizeof(float), hipMemcpyHostToDevice);
-      }
+   s->n_descs = desc_total;
+   s->n_gface_floats = gface_floats;
+   s->n_slots = slot_total;
+   e = hipMemset((float *) s->d_gfaces + 12 * gface_total, 0, 12 * (size_t) GFACE_PAD * sizeof(float));
+   if (e == hipSuccess) e = hipMemset((LeafDesc *) s->d_descs + desc_total, 0, DESC_PAD * sizeof(LeafDesc));
+   for (size_t i = 0; i < parts.size() && e == hipSuccess; i++) {
+      const ScenePart &part = parts[i];
+      if (!part.nodes.empty())
+         e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, part.nodes.data(), part.nodes.size() * sizeof(DevNodeRec), hipMemcpyHostToDevice);
+      if (e == hipSuccess && !part.groups.descs.empty())
+         e = hipMemcpy((LeafDesc *) s->d_descs + part.desc_base, part.groups.descs.data(), part.groups.descs.size() * sizeof(LeafDesc), hipMemcpyHostToDevice);
+      if (e == hipSuccess && !part.slot_face.empty())
+         e = hipMemcpy(s->d_slot_ids + part.slot_base, part.slot_face.data(), part.slot_face.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+      if (e == hipSuccess && !part.groups.gface.empty())   // the faces' corners, gathered on the device
+         e = gpu_emit_gfaces(objects[i].mesh.vertices, objects[i].mesh.n_vertices, objects[i].mesh.indices, objects[i].mesh.n_faces,
+                             part.groups.gface.data(), part.groups.gface.size(), (float *) s->d_gfaces + 12 * part.gface_base);
    }
    if (e == hipSuccess) e = hipDeviceSynchronize();
    return e;
@@ -536,7 +558,9 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    std::memset(&p, 0, sizeof(p));
    p.sc.objs = s->d_objs;
    p.sc.nodes = s->d_nodes;
-   p.sc.tris = s->d_tris;
+   p.sc.gfaces = s->d_gfaces;
+   p.sc.descs = s->d_descs;
+   p.sc.slot_ids = s->d_slot_ids;
    p.sc.fnrm = s->d_fnrm;
    p.sc.n_objs = (int32_t) s->objects.size();
    p.sc.epsilon = st->epsilon;
@@ -779,22 +803,12 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       std::memset(dev_objs.data(), 0, sizeof(DevObject) * dev_objs.size());
       std::vector<DevObjectExt> dev_ext(dev_objs.size());
       std::memset(dev_ext.data(), 0, sizeof(DevObjectExt) * dev_ext.size());
-      // all objects share one node array, one slot array and one normal array (links absolute); each object's part is
-      // built on the host (scene_build.cpp) or on the GPU (gpu_build.hip) and copied to its place at the end
+      // all objects share one array of each kind (links absolute); each object's part is built on the host (scene_build.cpp)
+      // or on the GPU (gpu_build.hip), grouped on the host and copied to its place at the end
       std::vector<ScenePart> parts(n_meshes ? n_meshes : 1);
-      struct PartsGuard {
-         std::vector<ScenePart> &parts;
-         ~PartsGuard()
-         {
-            for (ScenePart &p : parts) gpu_build_free(p.gpu);   // idempotent
-         }
-      } parts_guard { parts };
-      auto free_parts = [&parts]() {
-         for (ScenePart &p : parts) gpu_build_free(p.gpu);
-      };
       bool boxes_finite = true;
       std::vector<float> all_fnrm;
-      size_t slot_total = 0, face_total = 0, node_total = 0;
+      size_t slot_total = 0, face_total = 0, node_total = 0, desc_total = 0, gface_total = 0;
       const char *builder_env = getenv("MI355RT_BUILDER");   // "host": never build on the GPU (tuning / tests); default: GPU where it applies
       const bool allow_gpu_build = !(builder_env && std::string(builder_env) == "host");
 
@@ -812,8 +826,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             if (od.kind != MI355RT_OBJ_MESH) {
                const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
                if (!err.empty()) {
-                  free_parts();
-                  release_scene(s);
+                                    release_scene(s);
                   return fail(MI355RT_E_ARG, "object " + std::to_string(i) + ": " + err);
                }
                continue;
@@ -831,49 +844,63 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             const auto t_prep = std::chrono::steady_clock::now();
             const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo_obj, bo_out);
             if (!err.empty()) {
-               free_parts();
-               release_scene(s);
+                              release_scene(s);
                return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
             }
-            const size_t node_base = node_total, slot_base = slot_total, face_base = face_total;
+            const size_t face_base = face_total;
             uint64_t n_leaves = bo_out.n_leaves;
             int32_t tree_depth = bo_out.max_depth;
             const auto t_tree = std::chrono::steady_clock::now();
             if (gpu_build) {
                std::string gerr;
-               const hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj, part.gpu, gerr);
+               GpuBuiltObject built;
+               hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj, built, gerr);
+               if (ge == hipSuccess) {   // back to the host for the grouping pass
+                  part.nodes.resize((size_t) built.n_nodes);
+                  part.slot_face.resize((size_t) built.n_slots);
+                  ge = hipMemcpy(part.nodes.data(), built.nodes, sizeof(DevNodeRec) * part.nodes.size(), hipMemcpyDeviceToHost);
+                  if (ge == hipSuccess && built.n_slots)
+                     ge = hipMemcpy(part.slot_face.data(), built.slot_ids, sizeof(int32_t) * part.slot_face.size(), hipMemcpyDeviceToHost);
+               }
+               n_leaves = built.n_leaves;
+               tree_depth = built.max_depth;
+               gpu_build_free(built);
                if (ge != hipSuccess) {
-                  free_parts();
                   release_scene(s);
                   if (!gerr.empty()) return fail(MI355RT_E_LIMIT, "mesh " + std::to_string(i) + ": " + gerr);
                   return hip_fail(ge, "GPU hierarchy build");
                }
                part.on_gpu = true;
                s->any_gpu_build = true;
-               part.n_nodes = (size_t) part.gpu.n_nodes;
-               part.n_slots = (size_t) part.gpu.n_slots;
-               n_leaves = part.gpu.n_leaves;
-               tree_depth = part.gpu.max_depth;
+               part.root_link = 0;   // the GPU builder only takes meshes whose root splits: node 0
+               part.root_cnt = 0;
             } else {
-               part.n_nodes = bo_out.nodes.size();
-               part.n_slots = bo_out.slot_face.size();
+               host_part_records(bo_out, part);
             }
-            part.node_base = node_base;
-            part.slot_base = slot_base;
-            if (node_base + part.n_nodes > (size_t) 0x7ffffff0 || slot_base + part.n_slots > (size_t) 0x7ffffff0 ||
-                face_base + md.n_faces > (size_t) 0x7ffffff0) {
-               free_parts();
+            part.node_base = node_total;
+            part.slot_base = slot_total;
+            part.desc_base = desc_total;
+            part.gface_base = gface_total;
+            const bool root_is_leaf = !gpu_build && bo_out.root_is_leaf;
+            const int32_t root_faces = part.root_cnt;
+            finish_part(part, boxes_finite);
+            if (node_total + part.nodes.size() > (size_t) 0x3ffffff0 || slot_total + part.slot_face.size() > (size_t) 0x3ffffff0 ||
+                face_base + md.n_faces > (size_t) 0x3ffffff0 || gface_total + part.groups.gface.size() > (size_t) 0x3ffffff0) {
                release_scene(s);
-               return fail(MI355RT_E_LIMIT, "scene exceeds 2^31 nodes, leaf slots or faces");
+               return fail(MI355RT_E_LIMIT, "scene exceeds 2^30 nodes, leaf slots or faces");
             }
-            if (!gpu_build) host_part_records(bo_out, md, part, boxes_finite);
-            node_total += part.n_nodes;
-            slot_total += part.n_slots;
+            const size_t node_base = node_total, slot_base = slot_total;
+            node_total += part.nodes.size();
+            slot_total += part.slot_face.size();
+            desc_total += part.groups.descs.size();
+            gface_total += part.groups.gface.size();
+            s->n_groups += part.groups.n_groups;
+            s->n_shared_groups += part.groups.n_shared;
             if (getenv("MI355RT_BUILD_TIMING")) {   // profiling aid
                const auto t_end = std::chrono::steady_clock::now();
                std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + normals + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
                             gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
-                            gpu_build ? "GPU hierarchy" : "records", std::chrono::duration<double>(t_end - t_tree).count());
+                            gpu_build ? "GPU hierarchy + download + leaf groups" : "records + leaf groups", std::chrono::duration<double>(t_end - t_tree).count());
             }
             append_face_normals(all_fnrm, face_base, md, bo_out.normals);
             face_total += md.n_faces;
@@ -889,16 +916,17 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
             std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
             ho.shadow_distance = bo_out.shadow_distance;
-            ho.n_nodes = part.n_nodes;
+            ho.n_nodes = part.nodes.size();
             ho.n_leaves = n_leaves;
-            ho.n_slots = part.n_slots;
+            ho.n_slots = part.slot_face.size();
             ho.max_depth = tree_depth;
             ho.is_mesh = true;
             DevObject &d = dev_objs[i];
             d.kind = OBJ_MESH;
             std::memcpy(d.bmin, ho.bmin, sizeof(d.bmin));
             std::memcpy(d.bmax, ho.bmax, sizeof(d.bmax));
-            d.root_entry = (gpu_build || !bo_out.root_is_leaf) ? (int32_t) node_base : (bo_out.root_cnt > 0 ? ~(int32_t) slot_base : STACK_EMPTY);
+            // a leaf root: its first descriptor (group_leaves left it in root_link, relative to the part)
+            d.root_entry = !root_is_leaf ? (int32_t) node_base : (root_faces > 0 ? ~(int32_t) (part.desc_base + (size_t) part.root_link) : STACK_EMPTY);
             d.shadow_distance = bo_out.shadow_distance;
             d.face_base = (int32_t) face_base;
             d.node_base = (int32_t) node_base;
@@ -912,13 +940,11 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             }
          }
       } catch (const std::bad_alloc &) {
-         free_parts();
-         release_scene(s);
+                  release_scene(s);
          return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
       }
       {
-         const hipError_t e = upload_parts(s, parts, node_total, slot_total);
-         free_parts();
+         const hipError_t e = upload_parts(s, parts, objects, node_total, slot_total, desc_total, gface_total);
          if (e != hipSuccess) {
             release_scene(s);
             return hip_fail(e, "hierarchy upload");
@@ -1356,14 +1382,18 @@ int mi355rt_debug_scene_digest(mi355rt_scene *scene, uint64_t out[4])
       if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
       DeviceScope scope(scene->device);
       if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-      const void *src[3] = { scene->d_nodes, scene->d_tris, scene->d_fnrm };
-      const size_t bytes[3] = { scene->n_node_recs * sizeof(DevNodeRec), scene->n_tri_floats * sizeof(float), scene->n_fnrm_floats * sizeof(float) };
-      for (int k = 0; k < 3; k++) {
+      // out[1] runs over the three leaf arrays one after the other: descriptors, group faces, slot ids
+      const void *src[5] = { scene->d_nodes, scene->d_descs, scene->d_gfaces, scene->d_slot_ids, scene->d_fnrm };
+      const size_t bytes[5] = { scene->n_node_recs * sizeof(DevNodeRec), scene->n_descs * sizeof(LeafDesc), scene->n_gface_floats * sizeof(float),
+                                scene->n_slots * sizeof(int32_t), scene->n_fnrm_floats * sizeof(float) };
+      const int dst[5] = { 0, 1, 1, 1, 2 };
+      for (int k = 0; k < 3; k++) out[k] = 1469598103934665603ull;   // FNV-1a
+      for (int k = 0; k < 5; k++) {
          std::vector<unsigned char> host(bytes[k]);
          if (bytes[k]) HIP_TRY(hipMemcpy(host.data(), src[k], bytes[k], hipMemcpyDeviceToHost));
-         uint64_t h = 1469598103934665603ull;   // FNV-1a
+         uint64_t h = out[dst[k]];
          for (unsigned char c : host) h = (h ^ c) * 1099511628211ull;
-         out[k] = h;
+         out[dst[k]] = h;
       }
       out[3] = scene->any_gpu_build ? 1u : 0u;
       return MI355RT_OK;
@@ -1398,7 +1428,9 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
       std::memset(&a, 0, sizeof(a));
       a.sc.objs = scene->d_objs;
       a.sc.nodes = scene->d_nodes;
-      a.sc.tris = scene->d_tris;
+      a.sc.gfaces = scene->d_gfaces;
+      a.sc.descs = scene->d_descs;
+      a.sc.slot_ids = scene->d_slot_ids;
       a.sc.fnrm = scene->d_fnrm;
       a.sc.n_objs = (int32_t) scene->objects.size();
       a.sc.epsilon = settings->epsilon;

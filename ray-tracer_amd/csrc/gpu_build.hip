@@ -415,34 +415,32 @@ __global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, DevNodeRec
    r.rlink = link[1];
    r.lcnt = cnt[0];
    r.rcnt = cnt[1];
+   r.lgbase = r.rgbase = 0;   // filled in by the host's grouping pass (api.cpp finish_part)
+   r.lmask = r.rmask = 0u;
    out[nd.dfs] = r;
 }
 
-// leaf slots: { v0.xyz, faceId } { v1.xyz, faces left in the leaf from this slot on } { v2.xyz, index of the slot in its leaf }
-__global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face, const unsigned *store_node, unsigned n_store,
-                                  const float *vertices, const int32_t *indices, float *tris)
+// leaf slots in the reference's order: the face id of every (leaf, face) pair
+__global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face, const unsigned *store_node, unsigned n_store, int32_t *slot_ids)
 {
    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
    if (j >= n_store) return;
    const BNode &nd = nodes[store_node[j]];
-   const unsigned k = j - nd.store;
-   const unsigned face = store_face[j];
-   float4 *dst = (float4 *) tris + 3 * (size_t) (nd.sbase + k);
-   const int32_t *ix = indices + 3 * (size_t) face;
-   const float *a = vertices + 3 * (size_t) ix[0], *b = vertices + 3 * (size_t) ix[1], *c = vertices + 3 * (size_t) ix[2];
-   dst[0] = make_float4(a[0], a[1], a[2], __int_as_float((int) face));
-   dst[1] = make_float4(b[0], b[1], b[2], __int_as_float((int) (nd.count - k)));
-   dst[2] = make_float4(c[0], c[1], c[2], __int_as_float((int) k));
+   slot_ids[nd.sbase + (j - nd.store)] = (int32_t) store_face[j];
 }
 
-__global__ void relocate_nodes_kernel(const DevNodeRec *src, unsigned n, DevNodeRec *dst, int32_t node_base, int32_t slot_base)
+// group faces (layout.h): { v0.xyz, faceId } { v1.xyz, 0 } { v2.xyz, 0 } for every entry of the group-face list
+__global__ void emit_gfaces_kernel(const float *vertices, const int32_t *indices, const int32_t *gface, size_t n, float *out)
 {
-   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= n) return;
-   DevNodeRec r = src[i];
-   if (r.llink != LINK_NONE) r.llink += r.lcnt > 0 ? slot_base : node_base;
-   if (r.rlink != LINK_NONE) r.rlink += r.rcnt > 0 ? slot_base : node_base;
-   dst[i] = r;
+   const size_t j = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (j >= n) return;
+   const int32_t face = gface[j];
+   const int32_t *ix = indices + 3 * (size_t) face;
+   const float *a = vertices + 3 * (size_t) ix[0], *b = vertices + 3 * (size_t) ix[1], *c = vertices + 3 * (size_t) ix[2];
+   float4 *dst = (float4 *) out + 3 * j;
+   dst[0] = make_float4(a[0], a[1], a[2], __int_as_float((int) face));
+   dst[1] = make_float4(b[0], b[1], b[2], 0.0f);
+   dst[2] = make_float4(c[0], c[1], c[2], 0.0f);
 }
 
 // ---------------------------------------------------------------- host driver
@@ -494,7 +492,7 @@ template <typename T> hipError_t exclusive_scan(const T *in, size_t n, T *out, D
 void gpu_build_free(GpuBuiltObject &o)
 {
    if (o.nodes) (void) hipFree(o.nodes);
-   if (o.tris) (void) hipFree(o.tris);
+   if (o.slot_ids) (void) hipFree(o.slot_ids);
    o = GpuBuiltObject();
 }
 
@@ -583,28 +581,35 @@ hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const in
    out.n_leaves = root.n_leaves;
    out.max_depth = (int32_t) level_off.size() - 1;
    GB_TRY(hipMalloc((void **) &out.nodes, sizeof(DevNodeRec) * (size_t) out.n_nodes));
-   hipError_t e = hipMalloc((void **) &out.tris, sizeof(float) * 12 * (size_t) std::max<uint64_t>(out.n_slots, 1));
+   hipError_t e = hipMalloc((void **) &out.slot_ids, sizeof(int32_t) * (size_t) std::max<uint64_t>(out.n_slots, 1));
    if (e != hipSuccess) {
       gpu_build_free(out);
       return e;
    }
    hipLaunchKernelGGL(emit_nodes_kernel, dim3(grid_for(n_all)), dim3(256), 0, nullptr, nodes.p, (unsigned) n_all, out.nodes);
    hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(store_used)), dim3(256), 0, nullptr, nodes.p, store_face.p, store_node.p, (unsigned) store_used,
-                      d_vertices.p, d_indices.p, out.tris);
+                      out.slot_ids);
    e = hipGetLastError();
    if (e == hipSuccess) e = hipDeviceSynchronize();
    if (e != hipSuccess) gpu_build_free(out);
    return e;
 }
 
-hipError_t gpu_build_relocate(const GpuBuiltObject &o, DevNodeRec *dst_nodes, float *dst_tris, int32_t node_base, int32_t slot_base)
+hipError_t gpu_emit_gfaces(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, const int32_t *gface, size_t n,
+                           float *dst_dev)
 {
-   if (o.n_nodes)
-      hipLaunchKernelGGL(relocate_nodes_kernel, dim3(grid_for(o.n_nodes)), dim3(256), 0, nullptr, o.nodes, (unsigned) o.n_nodes, dst_nodes + node_base,
-                         node_base, slot_base);
+   if (!n) return hipSuccess;
+   DevVec<float> d_vertices;
+   DevVec<int32_t> d_indices, d_gface;
+   GB_TRY(d_vertices.ensure(3 * (size_t) n_vertices, 0));
+   GB_TRY(d_indices.ensure(3 * (size_t) n_faces, 0));
+   GB_TRY(d_gface.ensure(n, 0));
+   GB_TRY(hipMemcpy(d_vertices.p, vertices, sizeof(float) * 3 * (size_t) n_vertices, hipMemcpyHostToDevice));
+   GB_TRY(hipMemcpy(d_indices.p, indices, sizeof(int32_t) * 3 * (size_t) n_faces, hipMemcpyHostToDevice));
+   GB_TRY(hipMemcpy(d_gface.p, gface, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+   hipLaunchKernelGGL(emit_gfaces_kernel, dim3(grid_for(n)), dim3(256), 0, nullptr, d_vertices.p, d_indices.p, d_gface.p, n, dst_dev);
    hipError_t e = hipGetLastError();
-   if (e == hipSuccess && o.n_slots)
-      e = hipMemcpy(dst_tris + 12 * (size_t) slot_base, o.tris, sizeof(float) * 12 * (size_t) o.n_slots, hipMemcpyDeviceToDevice);
+   if (e == hipSuccess) e = hipDeviceSynchronize();   // the temporaries go out of scope
    return e;
 }
 

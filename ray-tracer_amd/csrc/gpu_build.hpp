@@ -13,7 +13,7 @@ namespace mi355rt {
 
 struct GpuBuiltObject {
    DevNodeRec *nodes = nullptr;   // n_nodes records in DFS pre-order; links relative to this object (node index / leaf first slot)
-   float *tris = nullptr;         // 12 floats per leaf slot, leaves in DFS order (layout.h)
+   int32_t *slot_ids = nullptr;   // face id per leaf slot, leaves in DFS order, faces in the reference's stored order
    uint64_t n_nodes = 0, n_leaves = 0, n_slots = 0;
    int32_t max_depth = 0;
 };
@@ -25,7 +25,8 @@ hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const in
                             const float bmax[3], const BuildOptions &opts, GpuBuiltObject &out, std::string &err);
 void gpu_build_free(GpuBuiltObject &o);
 
-// Copies a built object into the scene's shared arrays, making its links absolute.
-hipError_t gpu_build_relocate(const GpuBuiltObject &o, DevNodeRec *dst_nodes, float *dst_tris, int32_t node_base, int32_t slot_base);
+// Gathers the corners of the n faces listed in `gface` (host) into 48-byte group-face entries at dst_dev (layout.h "gfaces").
+hipError_t gpu_emit_gfaces(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, const int32_t *gface, size_t n,
+                           float *dst_dev);
 
 }   // namespace mi355rt

@@ -4,25 +4,34 @@
 // bounds/KDTree.java) is three arrays (NodeRec is the host builder's form, DevNodeRec what is uploaded):
 //
 // All objects' records are concatenated (links absolute); DevObject gives each object's root.
-//   nodes : one 64-byte record per INTERNAL node of the reference hierarchy, in DFS pre-order.
-//           A record carries the boxes and links of BOTH children, so one 4 x 128-bit fetch
+//   nodes : one 80-byte record per INTERNAL node of the reference hierarchy, in DFS pre-order.
+//           A record carries the boxes and links of BOTH children, so one 5 x 128-bit fetch
 //           decides both child tests (the reference tests left.minMax / right.minMax at the
 //           parent, bounds/KDNode.java:97,101).
 //             float4 a = { lmin.x, rmin.x, lmin.y, rmin.y }
 //             float4 b = { lmin.z, rmin.z, lmax.x, rmax.x }
 //             float4 c = { lmax.y, rmax.y, lmax.z, rmax.z }
 //             int4   d = { llink, rlink, lcnt, rcnt }
+//             int4   e = { lgbase, lmask, rgbase, rmask }   (leaf children: their descriptors' words, see LEAVES)
 //           The two children's values of one coordinate sit side by side (an aligned register pair after the
 //           128-bit load), so the walker's slab arithmetic runs both children through packed-f32 instructions
 //           (v_pk_add_f32 / v_pk_mul_f32: two results per issue slot).
-//           link: cnt == 0 -> index of the child's node record; cnt > 0 -> first leaf slot of a
+//           link: cnt == 0 -> index of the child's node record; cnt > 0 -> index of the first LEAF DESCRIPTOR of a
 //           leaf child holding cnt faces; link == LINK_NONE -> the reference's null child.
-//   tris  : one 48-byte slot per (leaf, face) pair, leaves in left-to-right DFS order, faces in
-//           the reference's stored order (straddlers are duplicated exactly as KDNode.java:58-69
-//           duplicates them).  slot = 3 x float4 { v0.xyz, faceId }, { v1.xyz, faces left in this leaf },
-//           { v2.xyz, index of the slot within its leaf }; LEAF_PAD_SLOTS zero slots follow the last leaf.
-//           Because leaves are laid out in DFS order, the first-slot index of a leaf is also the
-//           leaf's rank in the reference's fold order (the tie rule of KDNode.java:105,114).
+//   LEAVES (scene_build.hpp "leaf groups").  The reference's builder copies a face into every leaf whose box it
+//   straddles (KDNode.java:58-69: 6.9 leaf slots per face on the Dragon-class mesh).  Which leaves a ray reaches
+//   decides its answer, so the leaves stay; but a face that a ray misses, it misses in every leaf.  So:
+//   gfaces : 48 bytes per (group, distinct face): 3 x float4 { v0.xyz, faceId } { v1.xyz, 0 } { v2.xyz, 0 }.  A GROUP is
+//           a small subtree with at most 32 distinct faces (stored once, by ascending face id), or a single leaf
+//           (faces in the reference's stored order; 32 per group for larger leaves).
+//   descs : 16 bytes per leaf (per 32 faces of a larger leaf), leaves in left-to-right DFS order:
+//           { key, gbase | flags, mask, 0 }: key = the leaf's first SLOT in the reference's layout (one slot per
+//           (leaf, face), leaves in DFS order) -- the leaf's rank in the reference's fold order, which is all the tie
+//           rule of KDNode.java:105,114 needs --, gbase = the group's first entry in gfaces, mask = which of the
+//           group's faces the leaf holds.  The walker keeps, per lane, the faces of the current group its ray has
+//           already missed and tests only mask & ~missed.
+//   slot_ids : int32 per slot: the face id, in the reference's stored order (only read when two DIFFERENT faces of
+//           one leaf are hit at exactly the same distance: the earlier slot wins, KDNode.java:110-118).
 //   fnrm  : 48 bytes per FACE (not per slot): the three vertex normals, fetched once per final hit.
 //
 // FRAME SCRATCH (per scene handle, sized for one pass of at most `cap` samples).  The frame is a
@@ -43,10 +52,10 @@ namespace mi355rt {
 constexpr int32_t LINK_NONE = -1;
 constexpr int32_t STACK_EMPTY = 0x7fffffff;   // traversal cursor: nothing left (also the root entry of an empty mesh)
 constexpr int MAX_TREE_DEPTH = 22;   // build_opts.max_depth limit (the reference uses 20)
-constexpr int STACK_SLOTS = 24;      // >= MAX_TREE_DEPTH + 2
+constexpr int STACK_SLOTS = 22;      // >= MAX_TREE_DEPTH: at most one deferred sibling per level
 constexpr int MAX_OBJECTS = 64;
 constexpr int BLOCK_THREADS = 256;
-constexpr int LEAF_PAD_SLOTS = 8;    // zero slots after the last leaf: a walker may read a few slots past a leaf's end
+constexpr int GFACE_PAD = 2;         // zero entries after the last group face: lanes that sit a trip out read entry 0 / a second face that is not there
 
 struct NodeRec {   // 64 B
    float lmin[3], lmax[3];
@@ -55,12 +64,35 @@ struct NodeRec {   // 64 B
 };
 static_assert(sizeof(NodeRec) == 64, "node record must be 64 bytes");
 
-// the same record as uploaded: left / right interleaved per coordinate ([0] left, [1] right)
-struct DevNodeRec {   // 64 B
+// the same record as uploaded: left / right interleaved per coordinate ([0] left, [1] right), followed by a copy of each
+// LEAF child's descriptor words (group base | flags, mask; 0, 0 for a node child): a lane that steps into a leaf child
+// needs no fetch of its own for the descriptor, and a leaf none of whose faces is still untested costs nothing at all
+struct DevNodeRec {   // 80 B = 5 x float4
    float lo_x[2], lo_y[2], lo_z[2], hi_x[2], hi_y[2], hi_z[2];
    int32_t llink, rlink, lcnt, rcnt;
+   int32_t lgbase;
+   uint32_t lmask;
+   int32_t rgbase;
+   uint32_t rmask;
 };
-static_assert(sizeof(DevNodeRec) == 64, "node record must be 64 bytes");
+static_assert(sizeof(DevNodeRec) == 80, "node record must be 80 bytes");
+constexpr int NODE_F4 = 5;   // float4 per node record
+
+// leaf descriptors and groups (see LEAVES above)
+constexpr int GROUP_FACES = 32;     // bits of a leaf mask
+constexpr int GROUP_SLOTS = 224;    // a subtree with more leaf slots than this is not tried as one group
+constexpr int32_t DESC_MORE = (int32_t) 0x80000000;    // LeafDesc.gbase: the leaf goes on in the next descriptor
+constexpr int32_t DESC_IDENT = 0x40000000;             // LeafDesc.gbase: the group is this leaf (chunk) alone, its faces in slot order
+constexpr int32_t DESC_BASE_MASK = 0x3fffffff;
+constexpr int DESC_PAD = 3;         // descriptors after the last: the walker reads three float4 where one is the descriptor
+
+struct LeafDesc {   // 16 B, one per leaf (or per GROUP_FACES faces of a larger leaf)
+   int32_t key;     // first slot of the leaf: its rank in the reference's fold order (the tie rule) and where its face ids start
+   int32_t gbase;   // first entry of the leaf's group in the group-face array | DESC_MORE | DESC_IDENT
+   uint32_t mask;   // which of the group's faces the leaf holds
+   int32_t pad;
+};
+static_assert(sizeof(LeafDesc) == 16, "leaf descriptor must be 16 bytes");
 
 struct DevMaterial {
    uint32_t kind;
@@ -102,7 +134,9 @@ struct DevObject {
 struct SceneArgs {
    const DevObject *objs;
    const void *nodes;   // DevNodeRec[]
-   const void *tris;    // float4[3 * (n_slots + 1)]
+   const void *gfaces;  // float4[3 * (n_gfaces + GFACE_PAD)]
+   const void *descs;   // int4[n_descs]
+   const int32_t *slot_ids;   // [n_slots]
    const void *fnrm;    // float4[3 * n_faces]
    int32_t n_objs;
    float epsilon, near_plane, far_plane;

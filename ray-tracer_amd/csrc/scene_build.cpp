@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
+#include <utility>
 
 #include "host_math.hpp"
 
@@ -103,6 +105,130 @@ class Flattener {
 };
 
 }   // namespace
+
+namespace {
+
+// Both record forms (NodeRec, DevNodeRec) carry { llink, rlink, lcnt, rcnt } at byte 48: the grouper sees only those.
+struct Links {
+   int32_t llink, rlink, lcnt, rcnt;
+};
+
+class Grouper {
+ public:
+   Grouper(void *records, size_t n_records, size_t stride, const int32_t *slot_face, GroupedLeaves &out)
+      : rec_((unsigned char *) records), stride_(stride), slot_face_(slot_face), out_(out)
+   {
+      range_.resize(n_records);
+   }
+
+   // slot range [begin, end) of every subtree (leaves are laid out in DFS order, so a subtree's slots are one run)
+   void ranges(int32_t link, int32_t cnt, int32_t &b, int32_t &e)
+   {
+      if (cnt > 0) {
+         b = link;
+         e = link + cnt;
+         return;
+      }
+      const Links r = *at(link);
+      int32_t lb = -1, le = -1, rb = -1, re = -1;
+      if (r.llink != LINK_NONE) ranges(r.llink, r.lcnt, lb, le);
+      if (r.rlink != LINK_NONE) ranges(r.rlink, r.rcnt, rb, re);
+      b = lb >= 0 ? lb : rb;
+      e = re >= 0 ? re : le;
+      range_[(size_t) link] = { b, e };
+   }
+
+   // Walks the subtree under (link, cnt) in DFS order; returns the link the parent must store.
+   int32_t assign(int32_t link, int32_t cnt)
+   {
+      if (cnt > 0) return leaf_alone(link, cnt);
+      const int32_t b = range_[(size_t) link].first, e = range_[(size_t) link].second;
+      if (e - b <= GROUP_SLOTS) {
+         ids_.assign(slot_face_ + b, slot_face_ + e);
+         std::sort(ids_.begin(), ids_.end());
+         ids_.erase(std::unique(ids_.begin(), ids_.end()), ids_.end());
+         if ((int) ids_.size() <= GROUP_FACES) {
+            const int32_t gbase = (int32_t) out_.gface.size();
+            out_.gface.insert(out_.gface.end(), ids_.begin(), ids_.end());
+            out_.n_groups++;
+            out_.n_shared++;
+            in_group(link, gbase);
+            return link;
+         }
+      }
+      Links *r = at(link);
+      if (r->llink != LINK_NONE) r->llink = assign(r->llink, r->lcnt);
+      if (r->rlink != LINK_NONE) r->rlink = assign(r->rlink, r->rcnt);
+      return link;
+   }
+
+ private:
+   Links *at(int32_t node) const { return (Links *) (rec_ + stride_ * (size_t) node + 48); }
+
+   // a leaf that is its own group: GROUP_FACES faces per descriptor, in slot order
+   int32_t leaf_alone(int32_t first_slot, int32_t cnt)
+   {
+      const int32_t first_desc = (int32_t) out_.descs.size();
+      for (int32_t done = 0; done < cnt; done += GROUP_FACES) {
+         const int32_t n = std::min(GROUP_FACES, cnt - done);
+         LeafDesc d;
+         d.key = first_slot;
+         d.gbase = (int32_t) out_.gface.size() | DESC_IDENT | (done + n < cnt ? DESC_MORE : 0);
+         d.mask = n == 32 ? 0xffffffffu : ((1u << n) - 1u);
+         d.pad = 0;
+         out_.descs.push_back(d);
+         out_.gface.insert(out_.gface.end(), slot_face_ + first_slot + done, slot_face_ + first_slot + done + n);
+         out_.n_groups++;
+      }
+      return first_desc;
+   }
+
+   // every leaf under `link` becomes one descriptor: a mask over the group's faces (ids_, sorted), in DFS order
+   void in_group(int32_t link, int32_t gbase)
+   {
+      Links *r = at(link);
+      for (int side = 0; side < 2; side++) {
+         int32_t &l = side ? r->rlink : r->llink;
+         const int32_t c = side ? r->rcnt : r->lcnt;
+         if (l == LINK_NONE) continue;
+         if (c == 0) {
+            in_group(l, gbase);
+            continue;
+         }
+         LeafDesc d;
+         d.key = l;
+         d.gbase = gbase;
+         d.mask = 0;
+         d.pad = 0;
+         for (int32_t k = 0; k < c; k++) {
+            const int32_t f = slot_face_[(size_t) (l + k)];
+            d.mask |= 1u << (uint32_t) (std::lower_bound(ids_.begin(), ids_.end(), f) - ids_.begin());
+         }
+         l = (int32_t) out_.descs.size();
+         out_.descs.push_back(d);
+      }
+   }
+
+   unsigned char *rec_;
+   size_t stride_;
+   const int32_t *slot_face_;
+   GroupedLeaves &out_;
+   std::vector<std::pair<int32_t, int32_t>> range_;
+   std::vector<int32_t> ids_;
+};
+
+}   // namespace
+
+void group_leaves(void *records, size_t n_records, size_t stride, const int32_t *slot_face, int32_t &root_link, int32_t root_cnt, GroupedLeaves &out)
+{
+   static_assert(offsetof(NodeRec, llink) == 48 && offsetof(DevNodeRec, llink) == 48, "the grouper reads the links at byte 48 of a record");
+   out = GroupedLeaves();
+   if (root_cnt == 0 && n_records == 0) return;   // an empty mesh: no leaf at all
+   Grouper g(records, n_records, stride, slot_face, out);
+   int32_t b, e;
+   g.ranges(root_link, root_cnt, b, e);
+   root_link = g.assign(root_link, root_cnt);
+}
 
 void synthesise_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, float *out)
 {

@@ -33,6 +33,26 @@ struct BuiltObject {
 std::string build_object(const float *vertices, uint32_t n_vertices, const float *normals, const int32_t *indices,
                          uint32_t n_faces, const BuildOptions &opts, BuiltObject &out);
 
+// ---- leaf groups (layout.h "LEAVES"): what the walker reads instead of the raw leaf slots.
+// The reference's builder copies a face into every leaf whose box it straddles (6.9 leaves per face on the Dragon-class
+// mesh), so a ray that walks a handful of neighbouring leaves meets the same faces again and again -- 62 % of the
+// walker's triangle tests repeated one of the ray's last 32 faces.  A test that fails, fails in every leaf, so it need
+// only run once per ray.  The hierarchy itself must stay the reference's (which leaves a ray reaches decides its
+// answer); what changes is how a leaf names its faces: small subtrees are made GROUPS of at most GROUP_FACES distinct
+// faces, the group's faces are stored once, and each leaf of the group is a bit mask over them.  A lane keeps one
+// mask of the group faces its ray has already missed and skips them (trace_kernels.hip).
+struct GroupedLeaves {
+   std::vector<LeafDesc> descs;        // leaves in DFS order (a leaf of n > GROUP_FACES faces: ceil(n / GROUP_FACES) consecutive descriptors)
+   std::vector<int32_t> gface;         // face id of every group-face entry
+   uint64_t n_groups = 0, n_shared = 0;   // groups in all; groups that span more than one leaf
+};
+
+// Rewrites the leaf links of the records (first slot -> index of the leaf's first descriptor; node links and counts
+// stay) and fills `out`.  records: n_records NodeRec or DevNodeRec (`stride` bytes each) in DFS pre-order, links relative to this object;
+// slot_face: face id per leaf slot.  root_link / root_cnt: the root (node 0, or a leaf root's first slot and face count;
+// a leaf root is rewritten too).
+void group_leaves(void *records, size_t n_records, size_t stride, const int32_t *slot_face, int32_t &root_link, int32_t root_cnt, GroupedLeaves &out);
+
 // TriangleMesh.computeNormals, no-normals branch.
 void synthesise_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, float *out);
 

@@ -386,42 +386,48 @@ struct WalkArgs {
    int32_t count_index, cursor_index;   // first of N_BANDS counters / cursors
    uint32_t band_cap;                   // slots per band sub-queue
    int32_t stats;
-   int32_t refill_min;   // refill once this many lanes are idle (or all of them)
-   int32_t steal_min;    // while the queue still has rays: steal once this many lanes are idle
-   int32_t tail_steal_min;   // once the queue is dry: steal with this many idle lanes
-   int32_t age_min;      // shadow modes: idle lanes help a ray that has been walked for this many trips at once
-   int32_t both_min;     // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
-   int32_t resolve_min;  // MODE_CLOSEST: faces that passed the triangle tests wait in their lanes until this many lanes hold one
 };
 
 // lane roles
 enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_WAVES_PER_SIMD
-#define WALK_WAVES_PER_SIMD 6
+#define WALK_WAVES_PER_SIMD 5   // 96 VGPRs: the walker needs 86-90; held to 80 (6 waves) it spills 32 bytes per lane and loses more than the sixth wave gives
 #endif
 #ifndef WALK_SHADOW_SPREAD
 #define WALK_SHADOW_SPREAD 64   // power of two
 #endif
+#ifndef WALK_REFILL_MIN
+#define WALK_REFILL_MIN 24
+#endif
+#ifndef WALK_BOTH_MIN
+#define WALK_BOTH_MIN 12
+#endif
+#ifndef WALK_RESOLVE_MIN
+#define WALK_RESOLVE_MIN 12
+#endif
+#ifndef WALK_ADMIN_MIN
+#define WALK_ADMIN_MIN 6
+#endif
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
 #endif
-#ifndef DIAG_MAIL
-#define DIAG_MAIL 8
-#endif
-constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip (<= LEAF_PAD_SLOTS + 1)
+constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip
+static_assert(LEAF_BATCH == 2, "a leaf trip fetches two faces");
 
 template <int STATS, int MODE>   // STATS: 0 none, 1 counts + timeline (light), 2 + walker diagnostics (heavy, changes occupancy)
 __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(WALK_WAVES_PER_SIMD, WALK_WAVES_PER_SIMD))) void walk_kernel(const WalkArgs a)
 {
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
    __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
+   __shared__ int s_pkey[BLOCK_THREADS];                              // per lane: the leaf descriptor its waiting face (`pend`) was met in
    const int lane = threadIdx.x & 63;
    const int wave_base = threadIdx.x & ~63;
    int *__restrict__ stack = s_stack + threadIdx.x;
    volatile int *list = s_list + wave_base;
    uint32_t *cursors = a.counters + a.cursor_index;
    const float4 *__restrict__ nodes = (const float4 *) a.sc.nodes;
-   const float4 *__restrict__ tris = (const float4 *) a.sc.tris;
+   const float4 *__restrict__ gfaces = (const float4 *) a.sc.gfaces;
+   const float4 *__restrict__ descs = (const float4 *) a.sc.descs;
    const float nearp = a.sc.near_plane, farp = a.sc.far_plane, eps = a.sc.epsilon;
    const V3 light = mk3(a.light[0], a.light[1], a.light[2]);
    const int n_objs = a.sc.n_objs;
@@ -443,6 +449,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    } st;
    constexpr bool CLOSEST = MODE == MODE_CLOSEST || MODE == MODE_FUSED;   // rays come from the queue; faces wait in `pend`
    constexpr bool FUSED = MODE == MODE_FUSED;
+   // Thresholds, measured on the bench frame and its shares: they were launch arguments while they were being
+   // tuned; as constants they cost no scalar registers (the kernel is short of them: it spills scalars into vector lanes).
+   constexpr int REFILL_MIN = CLOSEST ? WALK_REFILL_MIN : 64;   // refill once this many lanes are idle (or all of them); shadow waves refill whole
+   constexpr int STEAL_MIN = CLOSEST ? 32 : 64;      // while the queue still has rays: steal once this many lanes are idle
+   constexpr int TAIL_STEAL_MIN = 1;                 // once the queue is dry: steal with this many idle lanes
+   constexpr int AGE_MIN = 8;                        // shadow modes: idle lanes help a ray that has been walked for this many trips at once
+   constexpr int BOTH_MIN = WALK_BOTH_MIN;           // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
+   constexpr int RESOLVE_MIN = CLOSEST ? WALK_RESOLVE_MIN : 1;   // faces that passed the triangle tests wait until this many lanes hold one
+   constexpr int ADMIN_MIN = WALK_ADMIN_MIN;         // lanes whose walk has ended wait until this many do before the bookkeeping block runs
    static_assert(MAX_OBJECTS <= 64, "k and mirror are 7-bit fields");
    st.role = ROLE_IDLE;
    st.owner = lane;      // the lane whose ray this lane is walking (itself unless ROLE_HELPER)
@@ -461,21 +476,44 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
    int pend = -1;         // MODE_CLOSEST: a face of the current object that passed the triangle tests and whose point and
-                          // distance are still to be computed: slot * 2 + (the next slot passed too); see "resolve" below
+                          // distance are still to be computed: its group-face entry | DESC_IDENT of its group (the leaf it
+                          // was met in waits in s_pkey); see "resolve" below
+   // leaves (layout.h "LEAVES"): cur < 0 is the leaf descriptor ~cur.  todo == 0: the descriptor is still to be read; else
+   // the faces of the leaf (bits over its group's faces) still to be tested.  gb: the descriptor's gbase word (group base
+   // and flags); missed: the faces of that group this lane's ray has been tested against and missed -- they miss in
+   // every leaf, so a leaf's work is its mask & ~missed.
+   int gb = -1;
+   unsigned missed = 0, todo = 0;
    bool resolve_req = false;   // wave-uniform: some lane found a second such face
    float lim2 = 0.0f;
    float ob_w = 0.0f, best_w = 0.0f;
-   int ob_slot = -1, ob_key = 0, best_slot = -1, best_obj = -1;
+   int ob_gf = -1, ob_key = 0, best_gf = -1, best_obj = -1;   // *_gf: group-face entry | DESC_IDENT
    bool occluded = false;
-   int s = 0;   // current slot while cur < 0 (cur stays ~first slot of the leaf, which is also the leaf's rank in fold order)
+   // The fold of KDNode.getChildIntersection restated order-independently (header comment): a candidate beats the object's
+   // best so far when it is nearer; at equal distance when its leaf comes later in the reference's order (key = the leaf's
+   // first slot); in one leaf, when its slot comes earlier (KDNode.java:110-118: the first face wins).  Slots of one leaf:
+   // a leaf that is its own group lists its faces in slot order; else the leaf's slot ids are searched (two DIFFERENT
+   // faces of one small leaf at exactly one distance: rays through a shared vertex or edge).
+   auto beats = [&](float dist, int key, int gfx) -> bool {
+      if (ob_gf < 0 || dist < ob_w) return true;
+      if (dist != ob_w) return false;
+      if (key != ob_key) return key > ob_key;
+      if (((gfx ^ ob_gf) & DESC_BASE_MASK) == 0) return false;
+      if (gfx & DESC_IDENT) return (gfx & DESC_BASE_MASK) < (ob_gf & DESC_BASE_MASK);
+      const int f_new = __float_as_int(gfaces[3 * (size_t) (gfx & DESC_BASE_MASK)].w), f_old = __float_as_int(gfaces[3 * (size_t) (ob_gf & DESC_BASE_MASK)].w);
+      for (int j = 0; j < 2 * GROUP_FACES; j++) {
+         const int f = a.sc.slot_ids[key + j];
+         if (f == f_new) return true;
+         if (f == f_old) return false;
+      }
+      return false;
+   };
    unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0, n_spawn = 0;
    unsigned n_box_s = 0, n_tri_s = 0;   // MODE_FUSED: tests made for shadow rays
    unsigned d_ray_trips = 0, d_ray_trips_max = 0;
    unsigned d_hist[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
    unsigned d_node_lane = 0, d_node_wave = 0, d_leaf_lane = 0, d_leaf_wave = 0, d_outer = 0, d_refill = 0, d_steal = 0;
-   int d_mail[DIAG_MAIL];
-   for (int e = 0; e < DIAG_MAIL; e++) d_mail[e] = -1;   // diagnostics: the last faces this lane's ray tested (how many tests are repeats?)
-   unsigned d_mail_pos = 0, d_repeat = 0;
+   unsigned d_repeat = 0;   // diagnostics: faces a leaf held that the ray had already missed in its group (tests saved)
    const unsigned long long t_begin = STATS ? wall_clock64() : 0ull;   // 100 MHz
    unsigned long long t_exhausted = 0ull;
    unsigned d_tail_trips = 0;   // wave trips after the queue ran dry
@@ -490,29 +528,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       // fold does not depend on when it happens (see the tie rule), and slots of one leaf still arrive in slot order.
       if (CLOSEST) {
          const unsigned long long pm = __ballot(pend >= 0);
-         if (pm != 0ull && (resolve_req || exhausted || (int) __popcll(pm) >= a.resolve_min || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
+         if (pm != 0ull && (resolve_req || exhausted || (int) __popcll(pm) >= RESOLVE_MIN || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
             const float sd = st.k >= 0 ? a.sc.objs[st.k].shadow_distance : 0.0f;
-            for (int pass = 0; pass < 2; pass++) {
-               const bool doit = pend >= 0 && (pass == 0 || (pend & 1));
-               if (pass == 1 && __ballot(doit) == 0ull) break;
-               if (doit) {
-                  const int slot = (pend >> 1) + pass;
-                  const float4 *t = tris + 3 * (size_t) slot;
-                  const float4 A = t[0], B = t[1], C = t[2];
-                  float u, v, dist;
-                  V3 P;
-                  (void) tri_test(A, B, C, r, eps, u, v, P, dist);
-                  const int key = slot - __float_as_int(C.w);   // first slot of the face's leaf
-                  if ((dist > sd) && (ob_slot < 0 || dist < ob_w || (dist == ob_w && key > ob_key))) {
-                     ob_w = dist;
-                     ob_slot = slot;
-                     ob_key = key;
-                     lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
-                     if (FUSED && st.shadow) {   // any accepted face occludes: the walk ends here
-                        sp = bot;
-                        cur = STACK_EMPTY;
-                        s = ~cur;
-                     }
+            if (pend >= 0) {
+               const float4 *t = gfaces + 3 * (size_t) (pend & DESC_BASE_MASK);
+               const float4 A = t[0], B = t[1], C = t[2];
+               float u, v, dist;
+               V3 P;
+               (void) tri_test(A, B, C, r, eps, u, v, P, dist);
+               const int key = __float_as_int(descs[(size_t) s_pkey[threadIdx.x]].x);
+               if ((dist > sd) && beats(dist, key, pend)) {
+                  ob_w = dist;
+                  ob_gf = pend;
+                  ob_key = key;
+                  lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
+                  if (FUSED && st.shadow) {   // any accepted face occludes: the walk ends here
+                     sp = bot;
+                     cur = STACK_EMPTY;
+                     todo = 0;
                   }
                }
             }
@@ -520,7 +553,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             resolve_req = false;
          }
       }
-      if (__ballot(cur == STACK_EMPTY) != 0ull) {
+      // The bookkeeping below serves lanes whose walk has just ended.  One ends somewhere in the wave nearly every trip, and
+      // the block is a hundred-odd instructions for the whole wave: ended lanes wait until admin_min of them do (or the
+      // idle ones suffice for a refill, or nothing else is left to walk, or the queue is dry and every lane counts).
+      const unsigned long long ended = __ballot(cur == STACK_EMPTY);
+      const int n_serve = __popcll(__ballot(cur == STACK_EMPTY && st.role != ROLE_IDLE));
+      if (ended != 0ull && (exhausted || n_serve >= ADMIN_MIN || ended == ~0ull || (n_serve == 0 && (int) __popcll(ended) >= REFILL_MIN))) {
          // ---- (1) helpers that finished their subtree hand (w, slot, leaf) to the ray's owner, which
          // folds it in with the same order-independent rule the leaves use
          unsigned long long fin = __ballot(st.role == ROLE_HELPER && cur == STACK_EMPTY);
@@ -530,12 +568,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             // h is wave-uniform: v_readlane (a few cycles) instead of a ds_bpermute round trip per value
             const int o = __builtin_amdgcn_readlane((int) st.owner, h);
             const float hw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ob_w), h));
-            const int hs = __builtin_amdgcn_readlane(ob_slot, h), hk = __builtin_amdgcn_readlane(ob_key, h);
+            const int hs = __builtin_amdgcn_readlane(ob_gf, h), hk = __builtin_amdgcn_readlane(ob_key, h);
             if (lane == o) {
                --st.pending;
-               if (hs >= 0 && (ob_slot < 0 || hw < ob_w || (hw == ob_w && hk > ob_key))) {
+               if (hs >= 0 && beats(hw, hk, hs)) {
                   ob_w = hw;
-                  ob_slot = hs;
+                  ob_gf = hs;
                   ob_key = hk;
                   lim2 = fminf(lim2, prune_limit2(r, hw, abs_max));
                }
@@ -550,11 +588,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // object's result, enter the next object or retire the ray
          if (st.role == ROLE_OWNER && cur == STACK_EMPTY && st.pending == 0) {
             bool redo_k = false;
-            if (st.k >= 0 && ob_slot >= 0) {
+            if (st.k >= 0 && ob_gf >= 0) {
                if (CLOSEST && !(FUSED && st.shadow)) {
                   if ((ob_w > eps) && (best_obj < 0 || ob_w < best_w)) {   // Camera.java:208
                      best_w = ob_w;
-                     best_slot = ob_slot;
+                     best_gf = ob_gf;
                      best_obj = st.k;
                   }
                } else if (MODE == MODE_SHADOW_ANY || FUSED) {
@@ -563,7 +601,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   if (ob_w < safe_w) {
                      occluded = true;   // shortcut 1 (device_util.h): the closest face is at most this far, and passes
                   } else {
-                     const float4 *t = tris + 3 * (size_t) ob_slot;
+                     const float4 *t = gfaces + 3 * (size_t) (ob_gf & DESC_BASE_MASK);
                      float u, v, dist;
                      V3 P;
                      (void) tri_test(t[0], t[1], t[2], r, eps, u, v, P, dist);
@@ -583,7 +621,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             if (!done) {
                st.k = nk;
                const DevObject *ob = a.sc.objs + st.k;
-               ob_slot = -1;
+               ob_gf = -1;
                ob_w = 0.0f;
                ob_key = 0;
                sp = bot = 0;
@@ -593,7 +631,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                if (STATS) (FUSED && st.shadow ? n_box_s : n_box)++;
                if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {
                   cur = ob->root_entry;   // KDTree.getChildIntersection (bounds/KDTree.java:59-65)
-                  s = ~cur;
+                  todo = 0;
                }
             } else {
                if (CLOSEST && !(FUSED && st.shadow)) st.unsaved = 1;
@@ -612,12 +650,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             if (um != 0ull) {
                const unsigned long long idle_now = __ballot(st.role == ROLE_IDLE);
                const int n_idle = __popcll(idle_now);
-               const bool refill_now = !exhausted && (n_idle >= a.refill_min || idle_now == ~0ull);
-               const bool steal_now = exhausted || n_idle >= a.steal_min;
+               const bool refill_now = !exhausted && (n_idle >= REFILL_MIN || idle_now == ~0ull);
+               const bool steal_now = exhausted || n_idle >= STEAL_MIN;
                if ((refill_now || steal_now) && st.unsaved) {
                   float4 h0 = make_float4(0, 0, 0, 0), h1 = make_float4(0, 0, 0, __int_as_float(-1));
                   if (best_obj >= 0) {
-                     const float4 *t = tris + 3 * (size_t) best_slot;
+                     const float4 *t = gfaces + 3 * (size_t) (best_gf & DESC_BASE_MASK);
                      const float4 A = t[0], B = t[1], C = t[2];
                      float u = 0, v = 0, dist = 0;
                      V3 P = mk3(0, 0, 0);
@@ -650,10 +688,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                      st.shadow = 1;
                      sp = bot = 0;
                      best_obj = -1;
-                     best_slot = -1;
+                     best_gf = -1;
                      best_w = 0.0f;
                      occluded = false;
                      age = 0;
+                     gb = -1;   // another ray: nothing is known to miss
+                     missed = 0;
                      if (STATS) n_spawn++;
                   }
                }
@@ -662,7 +702,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
 
          // ---- (3) idle lanes take new rays from the queue
          const unsigned long long idle = __ballot(st.role == ROLE_IDLE);
-         if (idle != 0ull && !exhausted && ((int) __popcll(idle) >= a.refill_min || idle == ~0ull)) {
+         if (idle != 0ull && !exhausted && ((int) __popcll(idle) >= REFILL_MIN || idle == ~0ull)) {
             const unsigned want_n = (unsigned) __popcll(idle);
             if (STATS > 1 && lane == 0) d_refill++;
             // A band's queue of n rays is dealt out as a rows x spread matrix read down the columns: logical index L
@@ -723,10 +763,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   st.redo = 0;
                   sp = bot = 0;
                   best_obj = -1;
-                  best_slot = -1;
+                  best_gf = -1;
                   best_w = 0.0f;
                   occluded = false;
                   age = 0;
+                  gb = -1;
+                  missed = 0;
                   if (STATS) n_ray++;
                   if (STATS > 1) {
                      d_ray_trips_max = max(d_ray_trips_max, d_ray_trips);
@@ -736,8 +778,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                         for (int q = 0; q < 8; q++) d_hist[q] += (q == bin) ? 1u : 0u;
                      }
                      d_ray_trips = 0;
-#pragma unroll
-                     for (int e = 0; e < DIAG_MAIL; e++) d_mail[e] = -1;
                   }
                }
             }
@@ -750,8 +790,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          // Before the queue is dry a steal needs steal_min idle lanes (they would rather wait for a refill) -- except,
          // for shadow rays, from a ray that has been walked for age_min trips already: those few long rays are what
          // the launch ends up waiting for, so they get help as soon as a lane is free.
-         const bool steal_any = (exhausted && (int) __popcll(thieves) >= a.tail_steal_min) || (int) __popcll(thieves) >= a.steal_min;
-         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || (!CLOSEST && age >= a.age_min)));   // measured: no gain for queue rays, fused or not
+         const bool steal_any = (exhausted && (int) __popcll(thieves) >= TAIL_STEAL_MIN) || (int) __popcll(thieves) >= STEAL_MIN;
+         const unsigned long long victims = __ballot(st.role != ROLE_IDLE && sp > bot && (steal_any || (!CLOSEST && age >= AGE_MIN)));   // measured: no gain for queue rays, fused or not
          if (thieves != 0ull && victims != 0ull) {
             const int n_pairs = min(__popcll(thieves), __popcll(victims));
             const int v_rank = rank_below(victims), t_rank = rank_below(thieves);
@@ -786,11 +826,13 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                st.plain = plain_ray(r) && a.sc.boxes_finite;
                age = v_age;
                cur = entry;
-               s = ~cur;
+               todo = 0;
                sp = bot = 0;
-               ob_slot = -1;
+               ob_gf = -1;
                ob_w = 0.0f;
                ob_key = 0;
+               gb = -1;
+               missed = 0;
                if (STATS > 1) d_steal++;
             }
             unsigned long long tm = __ballot(is_thief);
@@ -819,28 +861,28 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       const bool in_leaf = cur < 0;
       const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
       // once the queue is dry what counts is how soon the last rays end, not issue slots: nobody sits out
-      const bool both = exhausted || (n_node >= a.both_min && n_leaf >= a.both_min);
+      const bool both = exhausted || (n_node >= BOTH_MIN && n_leaf >= BOTH_MIN);
       const bool is_node = in_node && (both || n_node >= n_leaf);
       const bool is_leaf = in_leaf && (both || n_leaf > n_node);
-      // One fetch per lane per trip, issued up front for every lane so that the latencies overlap: a node lane
-      // reads its 64-byte record, a leaf lane the next LEAF_BATCH slots of its leaf (contiguous, 48 bytes each;
-      // the array is padded so that reading past the last leaf is harmless).  Lanes sitting the trip out read
-      // slot 0.  Testing several faces of a leaf per trip divides the number of dependent round trips to memory,
-      // which is what a leaf costs (the arithmetic is the same).
-      constexpr int NQ = 3 * LEAF_BATCH > 4 ? 3 * LEAF_BATCH : 4;
+      // One fetch per lane per trip, issued up front for every lane so that the latencies overlap: a node lane reads its
+      // 80-byte record; a leaf lane its 16-byte descriptor (a leaf that came off the stack; one entered from its parent
+      // has the words already) or the next two faces of the leaf it has not missed yet (48 bytes each, anywhere in its group's run of faces).  Lanes sitting the trip out read face 0.
+      // Testing two faces per trip halves the number of dependent round trips to memory, which is what a leaf costs.
+      constexpr int NQ = 6;
       float4 q[NQ];
       {
-         const float4 *src = is_node ? nodes + 4 * (size_t) cur : tris + 3 * (size_t) (is_leaf ? s : 0);
+         const bool want_desc = is_leaf && todo == 0u;
+         const unsigned rest = todo & (todo - 1u);
+         const size_t f0 = is_leaf && !want_desc ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) todo) - 1) : 0;
+         const size_t f1 = is_leaf && rest != 0u ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) rest) - 1) : f0;
+         const float4 *pa = is_node ? nodes + NODE_F4 * (size_t) cur : (want_desc ? descs + (size_t) ~cur : gfaces + 3 * f0);
+         const float4 *pb = is_node ? pa + 3 : gfaces + 3 * f1;
 #pragma unroll
-         for (int j = 0; j < 4; j++) q[j] = src[j];
-         if (NQ > 4) {
-#pragma unroll
-            for (int j = 4; j < NQ; j++) q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (is_leaf) {
-#pragma unroll
-               for (int j = 4; j < NQ; j++) q[j] = src[j];
-            }
-         }
+         for (int j = 0; j < 3; j++) q[j] = pa[j];   // (a descriptor is one float4: the array is padded for the other two)
+         q[3] = pb[0];
+         q[4] = pb[1];   // a node record's fifth float4: its leaf children's descriptor words
+         q[5] = make_float4(0.f, 0.f, 0.f, 0.f);
+         if (is_leaf) q[5] = pb[2];
       }
       const float4 na = q[0], nb = q[1], nc = q[2];
       const int4 nd = make_int4(__float_as_int(q[3].x), __float_as_int(q[3].y), __float_as_int(q[3].z), __float_as_int(q[3].w));
@@ -897,103 +939,128 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
             }
          }
-         const int le = nd.z > 0 ? ~nd.x : nd.x;   // stack / cursor form of each child: leaf = ~first_slot
+         const int le = nd.z > 0 ? ~nd.x : nd.x;   // stack / cursor form of each child: leaf = ~(its first descriptor)
          const int re = nd.w > 0 ? ~nd.y : nd.y;
+         // A leaf child's descriptor words ride in this record: what is left to test in it is known here.  A leaf all of
+         // whose faces this ray has already missed (in neighbouring leaves of its group) is no visit at all.
+         const int lg = __float_as_int(q[4].x), rg = __float_as_int(q[4].z);
+         const unsigned ltodo = __float_as_uint(q[4].y) & ~((((lg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
+         const unsigned rtodo = __float_as_uint(q[4].w) & ~((((rg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
+         if (nd.z > 0 && ltodo == 0u && !(lg & DESC_MORE)) {
+            if (STATS > 1 && lok) d_repeat += (unsigned) __popc(__float_as_uint(q[4].y));
+            lok = false;
+         }
+         if (nd.w > 0 && rtodo == 0u && !(rg & DESC_MORE)) {
+            if (STATS > 1 && rok) d_repeat += (unsigned) __popc(__float_as_uint(q[4].w));
+            rok = false;
+         }
+         int took = 0;   // 1 / 2: stepped into the left / right child; 0: back to the stack
          if (lok && rok) {
             // nearest child first; the order never decides WHETHER a child is visited
             const bool swap = tr < tl;
             cur = swap ? re : le;
+            took = swap ? 2 : 1;
             stack[sp * BLOCK_THREADS] = swap ? le : re;
             ++sp;
          } else if (lok) {
             cur = le;
+            took = 1;
          } else if (rok) {
             cur = re;
+            took = 2;
          } else if (sp > bot) {
             --sp;
             cur = stack[sp * BLOCK_THREADS];
          } else {
             cur = STACK_EMPTY;
          }
-         s = ~cur;
+         todo = 0u;   // a leaf off the stack reads its descriptor first
+         if (took != 0 && cur < 0) {
+            const int g = took == 1 ? lg : rg;
+            if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
+            if (STATS > 1) d_repeat += (unsigned) __popc((took == 1 ? __float_as_uint(q[4].y) : __float_as_uint(q[4].w)) & missed);
+            gb = g;
+            todo = took == 1 ? ltodo : rtodo;   // 0 only for a leaf that goes on in further descriptors: the leaf step moves on
+         }
       }
 
+      bool want_resolve = false;
       if (is_leaf) {
-         // (D) up to LEAF_BATCH faces of a leaf (KDNode.java:110-118), folded into object k's best in slot order.
-         // The slot's second float4 carries in .w how many faces of the leaf remain from that slot on.
+         // (D) a leaf (KDNode.java:110-118).  First trip: its descriptor -- which faces of its group it holds; the ones this
+         // ray has already missed (in a neighbouring leaf of the group) are not tested again.  Then two faces per trip,
+         // folded into object k's best by the order-independent rule (`beats`).
          if (STATS > 1) {
             d_leaf_lane++;
             if (first_active_lane()) d_leaf_wave++;
          }
-         const int n_left = __float_as_int(q[1].w);
-         bool stop = n_left <= LEAF_BATCH;
-         bool advance = true;
-         if (CLOSEST) {
-            static_assert(LEAF_BATCH == 2, "the pending-face word holds one slot and a flag for the next");
-            if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += n_left > 1 ? 2u : 1u;
-            if (STATS > 1) {
+         if (todo == 0u) {
+            const int g = __float_as_int(q[0].y);
+            const unsigned mask = __float_as_uint(q[0].z);
+            if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group (gb == -1: none yet)
+            gb = g;
+            todo = mask & ~missed;
+            if (STATS > 1) d_repeat += (unsigned) __popc(mask & missed);
+         } else {
+            const unsigned bit0 = todo & (0u - todo), rest = todo & (todo - 1u), bit1 = rest & (0u - rest);
+            const int gbase = gb & DESC_BASE_MASK;
+            unsigned done = bit0 | bit1;
+            if (CLOSEST) {
+               if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += bit1 ? 2u : 1u;
+               const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
+               const bool m1 = bit1 != 0u && tri_meets(q[3], q[4], q[5], r, eps);
+               missed |= (m0 ? 0u : bit0) | (m1 ? 0u : bit1);
+               if (m0 || m1) {
+                  if (pend < 0) {
+                     pend = (gbase + __ffs((int) (m0 ? bit0 : bit1)) - 1) | (gb & DESC_IDENT);
+                     s_pkey[threadIdx.x] = ~cur;
+                     if (m0 && m1) done = bit0;   // the second one is met again next trip, when the first has been worked out
+                  } else {
+                     done &= ~((m0 ? bit0 : 0u) | (m1 ? bit1 : 0u));   // one waits already: it is worked out first
+                  }
+               }
+               // a face that could not be noted, or a shadow ray's first face (if it is accepted the walk is over): resolve at once
+               want_resolve = done != (bit0 | bit1) || (FUSED && st.shadow && pend >= 0);
+            } else {
 #pragma unroll
-               for (int j = 0; j < 2; j++) {
-                  if (j == 0 || n_left > 1) {
-                     const int f = __float_as_int(q[3 * j].w) + (st.k << 24);
-                     bool seen = false;
-#pragma unroll
-                     for (int e = 0; e < DIAG_MAIL; e++) seen = seen || d_mail[e] == f;
-                     d_repeat += seen ? 1u : 0u;
-                     if (!seen) {
-#pragma unroll
-                        for (int e = 0; e < DIAG_MAIL; e++) d_mail[e] = (e == (int) (d_mail_pos % DIAG_MAIL)) ? f : d_mail[e];
-                        d_mail_pos++;
+               for (int j = 0; j < LEAF_BATCH; j++) {
+                  const unsigned bit = j ? bit1 : bit0;
+                  if (bit != 0u) {
+                     if (STATS) n_tri++;
+                     float u, v, dist;
+                     V3 P;
+                     const bool met = tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist);
+                     if (!met) missed |= bit;
+                     const int gfx = (gbase + __ffs((int) bit) - 1) | (gb & DESC_IDENT);
+                     const int key = met ? __float_as_int(descs[(size_t) ~cur].x) : 0;
+                     if (met && (dist > a.sc.objs[st.k].shadow_distance) && beats(dist, key, gfx)) {
+                        ob_w = dist;
+                        ob_gf = gfx;
+                        ob_key = key;
+                        lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
+                        if (MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {   // device_util.h, shortcut 1
+                           done = todo;          // nothing else in this leaf ...
+                           gb &= ~DESC_MORE;     // ... or the rest of it ...
+                           sp = bot;             // ... or anywhere else
+                           break;
+                        }
                      }
                   }
                }
             }
-            const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
-            const bool m1 = n_left > 1 && tri_meets(q[3], q[4], q[5], r, eps);
-            if (m0 || m1) {
-               if (pend < 0) {
-                  pend = ((s + (m0 ? 0 : 1)) << 1) | ((m0 && m1) ? 1 : 0);
-               } else {
-                  advance = false;   // one waits already: it is worked out first, then this pair of faces is tested again
-               }
-            }
-            // a shadow ray's first face is worked out at once: if it is accepted the walk is over
-            resolve_req = __ballot(!advance || (FUSED && st.shadow && pend >= 0)) != 0ull;
-         } else {
-#pragma unroll
-         for (int j = 0; j < LEAF_BATCH; j++) {
-            if (j < n_left) {
-               if (STATS) n_tri++;
-               float u, v, dist;
-               V3 P;
-               if (tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist) && (dist > a.sc.objs[st.k].shadow_distance) &&
-                   (ob_slot < 0 || dist < ob_w || (dist == ob_w && ~cur > ob_key))) {
-                  ob_w = dist;
-                  ob_slot = s + j;
-                  ob_key = ~cur;
-                  lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
-                  if (MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {   // device_util.h, shortcut 1
-                     stop = true;
-                     sp = bot;
-                     break;
-                  }
-               }
-            }
+            todo &= ~done;
          }
-         }
-         if (advance) {
-         s += LEAF_BATCH;
-         if (stop) {
-            if (sp > bot) {
+         if (todo == 0u) {   // this descriptor is finished: the leaf's next one, or back to the stack
+            if (gb & DESC_MORE) {
+               cur -= 1;   // ~(~cur + 1)
+            } else if (sp > bot) {
                --sp;
                cur = stack[sp * BLOCK_THREADS];
             } else {
                cur = STACK_EMPTY;
             }
-            s = ~cur;
-         }
          }
       }
+      if (CLOSEST) resolve_req = __ballot(want_resolve) != 0ull;
    }
 
    if (STATS) {
@@ -1512,13 +1579,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.cursor_index = cursor_index;
    a.band_cap = band_cap;
    a.stats = stats;
-   a.refill_min = tunable("MI355RT_REFILL_MIN", 24);
-   a.steal_min = tunable("MI355RT_STEAL_MIN", 32);
-   a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
-   a.both_min = tunable("MI355RT_BOTH_MIN", 12);
-   a.resolve_min = tunable("MI355RT_RESOLVE_MIN", 12);
-   a.age_min = 1 << 30;   // shadow launches only
-   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, 6));
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, WALK_WAVES_PER_SIMD));
    if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
    return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
 }
@@ -1575,12 +1636,6 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.cursor_index = cursor_index;
    a.band_cap = p.band_cap;
    a.stats = p.stats;
-   a.refill_min = tunable("MI355RT_REFILL_MIN_SHADOW", 64);   // shadow rays are short: a wave refills whole, and meanwhile helps its old rays (age_min)
-   a.steal_min = tunable("MI355RT_STEAL_MIN_SHADOW", 64);
-   a.tail_steal_min = tunable("MI355RT_TAIL_STEAL_MIN", 1);
-   a.both_min = tunable("MI355RT_BOTH_MIN", 12);
-   a.resolve_min = 1;
-   a.age_min = tunable("MI355RT_AGE_MIN", 8);
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream);
