@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 --pmc passes of bench.py into per-kernel HBM bytes per launch.
 
-usage: hbm_traffic.py KEY FETCH_DIR WRITE_DIR [TCC_DIR] > summary; also merges the result into
-profiles/hbm_traffic.json under KEY (bench.py reads roofline.traffic from there).
+usage: hbm_traffic.py KEY FETCH_DIR WRITE_DIR [TCC_DIR] [--json PATH] > summary; also merges the result into
+PATH (default profiles/hbm_traffic.json) under KEY (bench.py reads roofline.traffic from profiles/hbm_traffic.json).
 
 Rules (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): FETCH_SIZE and WRITE_SIZE are collected in
 separate passes (3 + 2 TCC slots), both are in KiB, and on gfx950 FETCH_SIZE tallies each 128-byte
 memory-side read request as 64 bytes, so it is doubled; WRITE_SIZE is taken as read.  The walkers gather
-64-byte node records and 48-byte leaf slots (16 bytes per lane, uncoalesced): the guide calls widths other
+80-byte node records and 48-byte group faces (16 bytes per lane, uncoalesced): the guide calls widths other
 than a coalesced stream uncalibrated, so the doubled figure is an upper bound for them."""
 import collections
 import csv
@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"walk_kernel<0, 0>": "walk_primary", "walk_kernel<0, 3>": "walk_primary", "walk_kernel<0, 2>": "walk_shadow", "walk_kernel<0, 1>": "walk_shadow",
-         "generate_kernel": "generate", "shade_kernel<0>": "shade", "phong_kernel": "phong", "resolve_kernel": "resolve"}
+         "generate_kernel": "generate", "shade_kernel<0>": "shade", "shade_kernel<1>": "shade", "phong_kernel": "phong", "resolve_kernel": "resolve"}
 
 
 def per_kernel(d):
@@ -34,10 +34,16 @@ def per_kernel(d):
 
 
 def main():
-    key, fetch_dir, write_dir = sys.argv[1:4]
+    argv = sys.argv[1:]
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if "--json" in argv:
+        i = argv.index("--json")
+        path = argv[i + 1]
+        del argv[i:i + 2]
+    key, fetch_dir, write_dir = argv[:3]
     fetch, n = per_kernel(fetch_dir)
     write, _ = per_kernel(write_dir)
-    tcc = per_kernel(sys.argv[4])[0] if len(sys.argv) > 4 else {}
+    tcc = per_kernel(argv[3])[0] if len(argv) > 3 else {}
     out = {}
     for k in fetch:
         rd = 2.0 * fetch[k]["FETCH_SIZE"] * 1024.0
@@ -52,7 +58,6 @@ def main():
             out[k]["l2_hit_rate"] = round(hit / max(hit + miss, 1.0), 4)
         print("%-14s launches=%-3d read=%8.1f MB (2 x FETCH_SIZE)  write=%8.1f MB  total=%8.1f MB%s"
               % (k, n[k], rd / 1e6, wr / 1e6, (rd + wr) / 1e6, "  L2 hit %.3f" % out[k]["l2_hit_rate"] if t else ""))
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     allj = json.load(open(path)) if os.path.exists(path) else {}
     allj[key] = out
     json.dump(allj, open(path, "w"), indent=1, sort_keys=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel issue figures from the SQ pass of tools/profile_round.sh (profiling helper, not a test).
 
-usage: sq_summary.py gpurun_out/prof_<tag>/sq > profiles/<tag>_sq_counters.txt"""
+usage: sq_summary.py gpurun_out/prof_<tag>/sq ["bench workload args"] > profiles/<tag>_sq_counters.txt"""
 import collections
 import csv
 import glob
@@ -21,7 +21,7 @@ for row in csv.DictReader(open(files[0])):
     acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
     calls[k].add(row["Dispatch_Id"])
 print("# rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAVES "
-      "-- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline --frames-in-flight 1")
+      "-- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --frames-in-flight 1 " + (sys.argv[2] if len(sys.argv) > 2 else ""))
 print("# per launch (averaged over the launches sampled); walk_kernel<1,*> is the one instrumented frame; SIMD VALU busy = "
       "4 cycles x SQ_INSTS_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines)")
 for k in order:
