@@ -312,8 +312,8 @@ def main():
     # exchange of frame k runs under the render of frame k + 1.  Every launch of the pipeline ends on its longest rays
     # with the chip draining; the next frame's bulk fills that in.  All ranks take part (the gathers are collectives).
     pipelined = None
-    if tile_world == world and args.frames_in_flight > 1:
-        pipelined = frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, W, H, rays_per_frame)
+    if args.frames_in_flight > 1:
+        pipelined = frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, tile_world, W, H, rays_per_frame)
 
     # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
     frame_verified = None
@@ -437,7 +437,7 @@ def shadow_any_hit_proven(scene, light):
     return float(np.linalg.norm(d)) > 1.01 * diag
 
 
-def frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, W, H, rays_per_frame):
+def frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, tile_world, W, H, rays_per_frame):
     """K frames with D in flight on every rank: D scene handles (each owns its scratch) on D streams, round robin, no host
     sync between; with N > 1 each frame's block is gathered asynchronously and unpacked on rank 0 when its buffer comes
     round again, so the exchange of frame k runs under the render of frame k + 1."""
@@ -460,7 +460,7 @@ def frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, W, 
             with torch.cuda.stream(streams[b]):
                 if pending[b]:
                     pending[b]()   # frame k - D: wait for its gather (stream-side), unpack on rank 0; then the block is free again
-                cams[b].render_device(frames[b], stream=streams[b].cuda_stream, tile_rank=rank, tile_world=world,
+                cams[b].render_device(frames[b], stream=streams[b].cuda_stream, tile_rank=rank, tile_world=tile_world,
                                       tile_size=tiles.DEFAULT_TILE, tile_compact=world > 1)
                 pending[b] = sh.gather(*outs[b], buffer=b, async_op=True) if world > 1 else None
 

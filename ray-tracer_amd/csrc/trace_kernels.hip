@@ -33,6 +33,7 @@
 #include "device_util.h"
 #include "kernels.h"
 #include "layout.h"
+#include "walk_args.h"
 
 namespace mi355rt {
 
@@ -370,24 +371,6 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
 // blockIdx % 8 (workgroups b and b + 8 share an XCD, hence an L2) and moves on to the next range
 // when its own is drained.  Queue order follows image order, so each L2 mostly sees one band of the
 // image.  Placement only affects speed: every ray is claimed exactly once whatever runs where.
-enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2, MODE_FUSED = 3 };
-
-struct WalkArgs {
-   SceneArgs sc;
-   const float *rays;        // MODE_CLOSEST: the queue
-   float *hits;
-   int32_t *hit_obj;
-   const float *hits0;       // shadow modes: primary hits, material/flag records, list of paths
-   float *mat0;
-   const uint32_t *shadow;
-   float light[3];
-   float light_prune_c;      // MODE_SHADOW: a box is hopeless when dist2(origin, box) > 1.0001 * far2(light, box) + this (device_util.h); NaN = never
-   uint32_t *counters;
-   int32_t count_index, cursor_index;   // first of N_BANDS counters / cursors
-   uint32_t band_cap;                   // slots per band sub-queue
-   int32_t stats;
-};
-
 // lane roles
 enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_WAVES_PER_SIMD
@@ -1549,9 +1532,20 @@ unsigned bounded_grid(int n_cus, unsigned long long max_items)
 
 namespace {
 
-template <int MODE>
-hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, hipStream_t stream)
+// MI355RT_WALKER=lds: the work-list walker (walk_lds.hip) instead of the lane walker below
+bool use_lds_walker()
 {
+   static const bool on = [] {
+      const char *v = getenv("MI355RT_WALKER");
+      return v && v[0] == 'l';
+   }();
+   return on;
+}
+
+template <int MODE>
+hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, hipStream_t stream, int n_cus = 0, unsigned long long max_items = 0)
+{
+   if (use_lds_walker() && n_cus > 0) return launch_walk_lds(a, MODE, n_cus, max_items, stats_level, stream);
    if (stats_level > 1) hipLaunchKernelGGL((walk_kernel<2, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
    else if (stats_level == 1) hipLaunchKernelGGL((walk_kernel<1, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
    else hipLaunchKernelGGL((walk_kernel<0, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
@@ -1580,8 +1574,8 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.band_cap = band_cap;
    a.stats = stats;
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, WALK_WAVES_PER_SIMD));
-   if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
-   return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream);
+   if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
+   return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
@@ -1638,8 +1632,8 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.stats = p.stats;
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
-   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream);
-   return launch_walk<MODE_SHADOW>(a, grid, level, stream);
+   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream, n_cus, max_items);
+   return launch_walk<MODE_SHADOW>(a, grid, level, stream, n_cus, max_items);
 }
 
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream)

@@ -1,0 +1,33 @@
+// walk_args.h -- what a walker launch is given: shared by the two walker kernels (trace_kernels.hip: one ray per lane;
+// walk_lds.hip: rays resident in LDS, work lists per phase).  Internal to libmi355rt.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "layout.h"
+
+namespace mi355rt {
+
+enum { MODE_CLOSEST = 0, MODE_SHADOW = 1, MODE_SHADOW_ANY = 2, MODE_FUSED = 3 };
+
+struct WalkArgs {
+   SceneArgs sc;
+   const float *rays;        // MODE_CLOSEST: the queue
+   float *hits;
+   int32_t *hit_obj;
+   const float *hits0;       // shadow modes: primary hits, material/flag records, list of paths
+   float *mat0;
+   const uint32_t *shadow;
+   float light[3];
+   float light_prune_c;      // MODE_SHADOW: a box is hopeless when dist2(origin, box) > 1.0001 * far2(light, box) + this (device_util.h); NaN = never
+   uint32_t *counters;
+   int32_t count_index, cursor_index;   // first of N_BANDS counters / cursors
+   uint32_t band_cap;                   // slots per band sub-queue
+   int32_t stats;
+};
+
+// walk_lds.hip: the same walks by the work-list kernel; mode = one of MODE_*, stats 0 / 1
+hipError_t launch_walk_lds(const WalkArgs &a, int mode, int n_cus, unsigned long long max_items, int stats, hipStream_t stream);
+
+}   // namespace mi355rt

@@ -13,7 +13,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.defaultdict(set)
 order = []
 for row in csv.DictReader(open(files[0])):
-    k = row["Kernel_Name"].split("(")[0].replace("void mi355rt::", "").replace("mi355rt::", "")
+    k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void mi355rt::", "").replace("mi355rt::", "")
     if "kernel" not in k or "at::" in k:
         continue
     if k not in acc:
