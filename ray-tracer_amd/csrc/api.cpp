@@ -158,6 +158,7 @@ struct mi355rt_scene {
    int n_analytic = 0;              // spheres + planes
    bool has_refraction = false;
    bool boxes_finite = true;        // see SceneArgs.boxes_finite
+   bool big_leaves = false;         // see SceneArgs.big_leaves
    bool any_gpu_build = false;
    size_t n_node_recs = 0, n_descs = 0, n_gface_floats = 0, n_slots = 0, n_fnrm_floats = 0;   // sizes of the arrays below
    void *d_nodes = nullptr, *d_descs = nullptr, *d_gfaces = nullptr, *d_fnrm = nullptr;   // all objects, concatenated (layout.h)
@@ -571,6 +572,7 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.sc.ext = s->d_ext;
    p.sc.n_analytic = s->n_analytic;
    p.sc.boxes_finite = s->boxes_finite ? 1 : 0;
+   p.sc.big_leaves = s->big_leaves ? 1 : 0;
    p.max_recursion_depth = st->max_recursion_depth;
    std::memcpy(p.origin, cam->origin, sizeof(p.origin));
    std::memcpy(p.rot, cam->rotation, sizeof(p.rot));
@@ -962,6 +964,14 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       }
       s->abs_max = n_meshes ? amax : 0.f;
       s->boxes_finite = boxes_finite;
+      {   // leaves of a dozen faces or more on average (a mesh of millions of faces under the reference's depth limit)
+         uint64_t leaves = 0, slots = 0;
+         for (const HostObject &o : s->objects) {
+            leaves += o.n_leaves;
+            slots += o.n_slots;
+         }
+         s->big_leaves = leaves > 0 && slots >= 12 * leaves;
+      }
       int rc;
       if ((rc = upload(dev_objs.data(), sizeof(DevObject) * dev_objs.size(), (void **) &s->d_objs, s)) ||
           (rc = upload(dev_ext.data(), sizeof(DevObjectExt) * dev_ext.size(), (void **) &s->d_ext, s))) {
@@ -1441,6 +1451,7 @@ int mi355rt_trace_rays(mi355rt_scene *scene, const mi355rt_settings *settings, u
       a.sc.ext = scene->d_ext;
       a.sc.n_analytic = scene->n_analytic;
       a.sc.boxes_finite = scene->boxes_finite ? 1 : 0;
+      a.sc.big_leaves = scene->big_leaves ? 1 : 0;
       a.n = (uint32_t) n;
       a.band_cap = (uint32_t) ((n + N_BANDS - 1) / N_BANDS);
       a.origins = (const float *) buf.p[0];

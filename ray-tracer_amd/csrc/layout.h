@@ -145,6 +145,7 @@ struct SceneArgs {
    const DevObjectExt *ext;   // [n_objs]
    int32_t n_analytic;        // spheres + planes among the objects
    int32_t boxes_finite;      // every node box is finite: rays with finite origin and 1/direction may take the packed slab test
+   int32_t big_leaves;        // the scene's leaves hold a dozen faces or more on average: the walker tests their chunks wave-wide
 };
 
 // Every queue is N_BANDS sub-queues of band_cap slots each: the pass's 8x8 pixel groups are cut into

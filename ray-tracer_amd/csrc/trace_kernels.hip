@@ -376,6 +376,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_WAVES_PER_SIMD
 #define WALK_WAVES_PER_SIMD 5   // 96 VGPRs: the walker needs 86-90; held to 80 (6 waves) it spills 32 bytes per lane and loses more than the sixth wave gives
 #endif
+#ifndef WALK_BIG_WAVES_PER_SIMD
+#define WALK_BIG_WAVES_PER_SIMD 5   // (6 waves at 80 VGPRs spill the burst's two passes in flight: Lucy-class 4K frame 54.1 ms at 5, 64.5 at 6)
+#endif
 #ifndef WALK_SHADOW_SPREAD
 #define WALK_SHADOW_SPREAD 64   // power of two
 #endif
@@ -391,14 +394,20 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_ADMIN_MIN
 #define WALK_ADMIN_MIN 6
 #endif
+#ifndef WALK_BURST_MIN
+#define WALK_BURST_MIN 8
+#endif
+#ifndef WALK_BURST_NODE_FEW
+#define WALK_BURST_NODE_FEW 8
+#endif
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
 #endif
 constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip
 static_assert(LEAF_BATCH == 2, "a leaf trip fetches two faces");
 
-template <int STATS, int MODE>   // STATS: 0 none, 1 counts + timeline (light), 2 + walker diagnostics (heavy, changes occupancy)
-__global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(WALK_WAVES_PER_SIMD, WALK_WAVES_PER_SIMD))) void walk_kernel(const WalkArgs a)
+template <int STATS, int MODE, int BIG>   // STATS: 0 none, 1 counts + timeline (light), 2 + walker diagnostics (heavy, changes occupancy); BIG: leaves of tens of faces (see "burst" below)
+__global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD, BIG ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD))) void walk_kernel(const WalkArgs a)
 {
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
    __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
@@ -432,6 +441,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    } st;
    constexpr bool CLOSEST = MODE == MODE_CLOSEST || MODE == MODE_FUSED;   // rays come from the queue; faces wait in `pend`
    constexpr bool FUSED = MODE == MODE_FUSED;
+   constexpr bool DEFER = CLOSEST || BIG != 0;   // faces that pass the triangle tests wait in `pend` for the resolve block
    // Thresholds, measured on the bench frame and its shares: they were launch arguments while they were being
    // tuned; as constants they cost no scalar registers (the kernel is short of them: it spills scalars into vector lanes).
    constexpr int REFILL_MIN = CLOSEST ? WALK_REFILL_MIN : 64;   // refill once this many lanes are idle (or all of them); shadow waves refill whole
@@ -440,6 +450,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
    constexpr int AGE_MIN = 8;                        // shadow modes: idle lanes help a ray that has been walked for this many trips at once
    constexpr int BOTH_MIN = WALK_BOTH_MIN;           // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
    constexpr int RESOLVE_MIN = CLOSEST ? WALK_RESOLVE_MIN : 1;   // faces that passed the triangle tests wait until this many lanes hold one
+   constexpr int BURST_MIN = WALK_BURST_MIN, BURST_NODE_FEW = WALK_BURST_NODE_FEW;   // BIG: see "burst"
    constexpr int ADMIN_MIN = WALK_ADMIN_MIN;         // lanes whose walk has ended wait until this many do before the bookkeeping block runs
    static_assert(MAX_OBJECTS <= 64, "k and mirror are 7-bit fields");
    st.role = ROLE_IDLE;
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       // only notes the slot; here, once enough lanes hold one (or a lane needs its answer: its walk of the object is
       // over, or it found another face), all of them are worked out together and folded into the lane's best.  The
       // fold does not depend on when it happens (see the tie rule), and slots of one leaf still arrive in slot order.
-      if (CLOSEST) {
+      if (DEFER) {
          const unsigned long long pm = __ballot(pend >= 0);
          if (pm != 0ull && (resolve_req || exhausted || (int) __popcll(pm) >= RESOLVE_MIN || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
             const float sd = st.k >= 0 ? a.sc.objs[st.k].shadow_distance : 0.0f;
@@ -525,7 +536,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
                   ob_gf = pend;
                   ob_key = key;
                   lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
-                  if (FUSED && st.shadow) {   // any accepted face occludes: the walk ends here
+                  // any accepted face occludes (any-hit forms), or one safely before half way to the light
+                  // (device_util.h, shortcut 1): the walk ends here
+                  if ((FUSED && st.shadow) || MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {
                      sp = bot;
                      cur = STACK_EMPTY;
                      todo = 0;
@@ -844,7 +857,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       const bool in_leaf = cur < 0;
       const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
       // once the queue is dry what counts is how soon the last rays end, not issue slots: nobody sits out
-      const bool both = exhausted || (n_node >= BOTH_MIN && n_leaf >= BOTH_MIN);
+      const bool both = BIG || exhausted || (n_node >= BOTH_MIN && n_leaf >= BOTH_MIN);
       const bool is_node = in_node && (both || n_node >= n_leaf);
       const bool is_leaf = in_leaf && (both || n_leaf > n_node);
       // One fetch per lane per trip, issued up front for every lane so that the latencies overlap: a node lane reads its
@@ -856,8 +869,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       {
          const bool want_desc = is_leaf && todo == 0u;
          const unsigned rest = todo & (todo - 1u);
-         const size_t f0 = is_leaf && !want_desc ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) todo) - 1) : 0;
-         const size_t f1 = is_leaf && rest != 0u ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) rest) - 1) : f0;
+         // (BIG: a leaf's faces are fetched by the lanes that test them, in the burst below)
+         const size_t f0 = !BIG && is_leaf && !want_desc ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) todo) - 1) : 0;
+         const size_t f1 = !BIG && is_leaf && rest != 0u ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) rest) - 1) : f0;
          const float4 *pa = is_node ? nodes + NODE_F4 * (size_t) cur : (want_desc ? descs + (size_t) ~cur : gfaces + 3 * f0);
          const float4 *pb = is_node ? pa + 3 : gfaces + 3 * f1;
 #pragma unroll
@@ -865,7 +879,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
          q[3] = pb[0];
          q[4] = pb[1];   // a node record's fifth float4: its leaf children's descriptor words
          q[5] = make_float4(0.f, 0.f, 0.f, 0.f);
-         if (is_leaf) q[5] = pb[2];
+         if (!BIG && is_leaf) q[5] = pb[2];
       }
       const float4 na = q[0], nb = q[1], nc = q[2];
       const int4 nd = make_int4(__float_as_int(q[3].x), __float_as_int(q[3].y), __float_as_int(q[3].z), __float_as_int(q[3].w));
@@ -968,7 +982,114 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
       }
 
       bool want_resolve = false;
-      if (is_leaf) {
+      if (BIG) {
+         // (D') leaves of tens of faces (the reference's depth limit of 20 on a mesh of millions: layout.h chunks of up to
+         // 32 faces).  Two faces per lane and trip would leave a leaf lane sixteen trips in one chunk with the node lanes
+         // masked off beside it.  Instead the WAVE tests chunks: each pass takes the next two leaf lanes, broadcasts their
+         // rays, and lane j of each half tests face j of that lane's chunk -- 64 triangle tests per pass at full lane use.
+         // The chunk's owner gets the mask of faces that passed; the first waits in `pend` (resolved at the top of the
+         // next trip), any others stay in `todo` and are met again.  Which lane tests a face cannot matter: the tests
+         // read only the ray and the face, and the fold is order independent.
+         if (is_leaf && todo == 0u) {
+            const int g = __float_as_int(q[0].y);
+            const unsigned mask = __float_as_uint(q[0].z);
+            if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group (gb == -1: none yet)
+            gb = g;
+            todo = mask & ~missed;
+         }
+         // A burst is a hundred-odd instructions per pass for the whole wave, and a node step a few dozen: the lanes at
+         // nodes go on walking (cheap trips) until enough lanes wait with a chunk, or few lanes are at nodes.
+         unsigned long long el = __ballot(is_leaf && todo != 0u);
+         if ((int) __popcll(el) < BURST_MIN && n_node >= BURST_NODE_FEW && !exhausted) el = 0ull;
+         // A pass packs the chunks of the next few leaf lanes side by side over the 64 lanes: a chunk of n faces (bits
+         // 0 .. n-1 of `todo`; n = its highest face + 1) takes n lanes, and lane `base + j` tests face j.  The passes are
+         // software-pipelined: the faces of the next pass are on their way while this one is tested.
+         struct Pass {
+            int src, base;      // per lane: the leaf lane whose chunk this lane tests a face of (-1: none), first lane of that chunk
+            int my_base;        // per leaf lane: first lane of its chunk in this pass (-1: not in this pass)
+            bool have;
+            float4 fA, fB, fC;
+         };
+         auto next_pass = [&](Pass &ps) {
+            int off = 0;
+            ps.src = -1;
+            ps.base = 0;
+            ps.my_base = -1;
+            while (el != 0ull) {
+               const int sl = __ffsll((unsigned long long) el) - 1;
+               const int len = 32 - __clz(__builtin_amdgcn_readlane((int) todo, sl));
+               if (off + len > 64) break;
+               el &= el - 1ull;
+               if (lane >= off) {
+                  ps.src = sl;
+                  ps.base = off;
+               }
+               if (lane == sl) ps.my_base = off;
+               off += len;
+            }
+            if (lane >= off) ps.src = -1;
+            const int from = ps.src >= 0 ? ps.src : lane;
+            const unsigned s_todo = (unsigned) __shfl((int) todo, from, 64);
+            const int s_gb = __shfl(gb, from, 64);
+            const int j = lane - ps.base;
+            ps.have = ps.src >= 0 && ((s_todo >> j) & 1u) != 0u;
+            const float4 *t = gfaces + 3 * (ps.have ? (size_t) (s_gb & DESC_BASE_MASK) + (size_t) j : (size_t) 0);
+            ps.fA = t[0];
+            ps.fB = t[1];
+            ps.fC = t[2];
+         };
+         auto test_pass = [&](const Pass &pc) {
+            const int from = pc.src >= 0 ? pc.src : lane;
+            Ray sr;
+            sr.o = mk3(__shfl(r.o.x, from, 64), __shfl(r.o.y, from, 64), __shfl(r.o.z, from, 64));
+            sr.d = mk3(__shfl(r.d.x, from, 64), __shfl(r.d.y, from, 64), __shfl(r.d.z, from, 64));
+            sr.inv = sr.d;   // not used by the triangle tests
+            const bool met = pc.have && tri_meets(pc.fA, pc.fB, pc.fC, sr, eps);
+            const unsigned long long bal = __ballot(met);
+            if (pc.my_base >= 0) {
+               const unsigned passed = (unsigned) (bal >> pc.my_base) & todo;   // (the lanes above this chunk's belong to the next one)
+               if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += (unsigned) __popc(todo);
+               missed |= todo & ~passed;
+               if (passed != 0u) {
+                  if (pend < 0) {
+                     const unsigned first = passed & (0u - passed);
+                     pend = ((gb & DESC_BASE_MASK) + __ffs((int) first) - 1) | (gb & DESC_IDENT);
+                     s_pkey[threadIdx.x] = ~cur;
+                     todo = passed & ~first;
+                  } else {
+                     todo = passed;   // one waits already: it is worked out first
+                  }
+                  want_resolve = todo != 0u || (FUSED && st.shadow);   // faces that could not be noted, or a shadow ray's first face
+               } else {
+                  todo = 0u;
+               }
+            }
+         };
+         if (el != 0ull) {
+            Pass p0, p1;   // ping-pong: one is tested while the other's faces arrive
+            next_pass(p0);
+            for (;;) {
+               bool more = el != 0ull;
+               if (more) next_pass(p1);
+               test_pass(p0);
+               if (!more) break;
+               more = el != 0ull;
+               if (more) next_pass(p0);
+               test_pass(p1);
+               if (!more) break;
+            }
+         }
+         if (is_leaf && todo == 0u) {   // this chunk is finished: the leaf's next one, or back to the stack
+            if (gb & DESC_MORE) {
+               cur -= 1;
+            } else if (sp > bot) {
+               --sp;
+               cur = stack[sp * BLOCK_THREADS];
+            } else {
+               cur = STACK_EMPTY;
+            }
+         }
+      } else if (is_leaf) {
          // (D) a leaf (KDNode.java:110-118).  First trip: its descriptor -- which faces of its group it holds; the ones this
          // ray has already missed (in a neighbouring leaf of the group) are not tested again.  Then two faces per trip,
          // folded into object k's best by the order-independent rule (`beats`).
@@ -1043,7 +1164,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(W
             }
          }
       }
-      if (CLOSEST) resolve_req = __ballot(want_resolve) != 0ull;
+      if (DEFER) resolve_req = __ballot(want_resolve) != 0ull;
    }
 
    if (STATS) {
@@ -1532,6 +1653,14 @@ unsigned bounded_grid(int n_cus, unsigned long long max_items)
 
 namespace {
 
+// Leaves of tens of faces (meshes of millions of faces under the reference's depth limit) take the walker's burst form.
+// MI355RT_BIG_LEAVES=0/1 forces either form (the tests run both and require identical frames).
+bool big_leaves(const SceneArgs &sc)
+{
+   const char *v = getenv("MI355RT_BIG_LEAVES");   // read per launch: the tests switch it between frames
+   return v && *v ? atoi(v) != 0 : sc.big_leaves != 0;
+}
+
 // MI355RT_WALKER=lds: the work-list walker (walk_lds.hip) instead of the lane walker below
 bool use_lds_walker()
 {
@@ -1546,9 +1675,14 @@ template <int MODE>
 hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, hipStream_t stream, int n_cus = 0, unsigned long long max_items = 0)
 {
    if (use_lds_walker() && n_cus > 0) return launch_walk_lds(a, MODE, n_cus, max_items, stats_level, stream);
-   if (stats_level > 1) hipLaunchKernelGGL((walk_kernel<2, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
-   else if (stats_level == 1) hipLaunchKernelGGL((walk_kernel<1, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
-   else hipLaunchKernelGGL((walk_kernel<0, MODE>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   if (big_leaves(a.sc)) {   // (no diagnostics build of this form: level 2 counts as level 1)
+      if (stats_level >= 1) hipLaunchKernelGGL((walk_kernel<1, MODE, 1>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+      else hipLaunchKernelGGL((walk_kernel<0, MODE, 1>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+      return hipGetLastError();
+   }
+   if (stats_level > 1) hipLaunchKernelGGL((walk_kernel<2, MODE, 0>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   else if (stats_level == 1) hipLaunchKernelGGL((walk_kernel<1, MODE, 0>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
+   else hipLaunchKernelGGL((walk_kernel<0, MODE, 0>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
    return hipGetLastError();
 }
 
@@ -1573,7 +1707,7 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.cursor_index = cursor_index;
    a.band_cap = band_cap;
    a.stats = stats;
-   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, WALK_WAVES_PER_SIMD));
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, big_leaves(sc) ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD));
    if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
    return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
 }
@@ -1630,7 +1764,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.cursor_index = cursor_index;
    a.band_cap = p.band_cap;
    a.stats = p.stats;
-   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, 4));
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, big_leaves(p.sc) ? WALK_BIG_WAVES_PER_SIMD : 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream, n_cus, max_items);
    return launch_walk<MODE_SHADOW>(a, grid, level, stream, n_cus, max_items);
