@@ -313,7 +313,7 @@ def main():
     # with the chip draining; the next frame's bulk fills that in.  All ranks take part (the gathers are collectives).
     pipelined = None
     if args.frames_in_flight > 1:
-        pipelined = frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, tile_world, W, H, rays_per_frame)
+        pipelined = frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame)
 
     # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
     frame_verified = None
@@ -437,49 +437,25 @@ def shadow_any_hit_proven(scene, light):
     return float(np.linalg.norm(d)) > 1.01 * diag
 
 
-def frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, tile_world, W, H, rays_per_frame):
-    """K frames with D in flight on every rank: D scene handles (each owns its scratch) on D streams, round robin, no host
-    sync between; with N > 1 each frame's block is gathered asynchronously and unpacked on rank 0 when its buffer comes
-    round again, so the exchange of frame k runs under the render of frame k + 1."""
+def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame):
+    """K frames with D in flight on every rank (tiles.FramePipeline): D views of the scene (mi355rt_scene_view: shared
+    arrays, own scratch) on D streams, round robin, no host sync between; with N > 1 each frame's block is gathered
+    asynchronously and unpacked on rank 0 when its slot comes round again, so the exchange of frame k runs under the
+    render of frame k + 1."""
     D = args.frames_in_flight
-    scenes = [rt.Scene(objects, light, cfg["orientation"], rt.PhongLightingModel(light, objects), cfg["fov"], device=dev.index) for _ in range(D)]
-    cams = [rt.Camera(s, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024) for s in scenes]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
-    sh = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev, n_buffers=D)
+    pipe = tiles.FramePipeline(scene, lambda sc: rt.Camera(sc, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024),
+                               W, H, rank, world, D, tiles.DEFAULT_TILE, dev, tile_world=tile_world)
     full = rank == 0
-    outs = [[torch.zeros((H, W, 3), dtype=torch.float32, device=dev), torch.zeros((H, W), dtype=torch.int32, device=dev),
-             torch.zeros((H, W), dtype=torch.int32, device=dev), torch.zeros((H, W), dtype=torch.float32, device=dev)] if (full or world == 1)
-            else [None] * 4 for _ in range(D)]
-    frames = [rt._abi.Frame(o[0].data_ptr(), None, o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr()) if world == 1 else sh.blocks[b].frame()
-              for b, o in enumerate(outs)]
-    pending = [None] * D
-
-    def run(n):
-        for k in range(n):
-            b = k % D
-            with torch.cuda.stream(streams[b]):
-                if pending[b]:
-                    pending[b]()   # frame k - D: wait for its gather (stream-side), unpack on rank 0; then the block is free again
-                cams[b].render_device(frames[b], stream=streams[b].cuda_stream, tile_rank=rank, tile_world=tile_world,
-                                      tile_size=tiles.DEFAULT_TILE, tile_compact=world > 1)
-                pending[b] = sh.gather(*outs[b], buffer=b, async_op=True) if world > 1 else None
-
-    def drain():
-        for b in range(D):
-            if pending[b]:
-                with torch.cuda.stream(streams[b]):
-                    pending[b]()
-                pending[b] = None
-        torch.cuda.synchronize()
-
-    run(2 * D)
-    drain()
+    for _ in range(2 * D):
+        pipe.submit()
+    pipe.drain()
     if world > 1:
         dist.barrier()
     n = max(args.steps, 2 * D)
     t0 = time.perf_counter()
-    run(n)
-    drain()
+    for _ in range(n):
+        pipe.submit()
+    pipe.drain()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -488,14 +464,15 @@ def frames_in_flight(rt, tiles, args, objects, light, cfg, dev, rank, world, til
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     dt /= n
+    outs = pipe.outs
     same = all(bool(torch.equal(a, b)) for o in outs[1:] for a, b in zip(o, outs[0])) if (full or world == 1) else None
-    for s in scenes:
-        s.close()
     res = {"frames_in_flight": D, "steps": n, "ms_per_step": round(dt * 1e3, 4), "value": round(rays_per_frame / dt / 1e6, 2),
-           "unit": "Mrays/s", "frames_identical": same,
+           "unit": "Mrays/s", "frames_identical": same, "views_of_one_scene": True,
            "note": "not the headline value: frames overlap, so a frame's launch tails (and, with N > 1, its exchange) are filled by the next frame's bulk"}
     if world > 1 and full:
-        res["_frames_equal"] = lambda single: all(bool(torch.equal(a, b)) for a, b in zip(single, outs[0]))
+        keep = [t.clone() for t in outs[0]]
+        res["_frames_equal"] = lambda single: all(bool(torch.equal(a, b)) for a, b in zip(single, keep))
+    pipe.close()
     return res
 
 

@@ -21,9 +21,10 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 6   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
+#define MI355RT_ABI_VERSION 7   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
                                  * 4: mi355rt_render_device_noalloc; 5: mi355rt_render returns hit_obj, mi355rt_mesh_desc.compute_kdtree;
-                                 * 6: mi355rt_settings.tile_compact, mi355rt_tiles_unpack_device */
+                                 * 6: mi355rt_settings.tile_compact, mi355rt_tiles_unpack_device;
+                                 * 7: mi355rt_scene_view */
 
 enum {
    MI355RT_OK = 0,
@@ -181,6 +182,17 @@ int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, con
 int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_objects, const mi355rt_build_opts *opts,
                                  mi355rt_scene **out);
 void mi355rt_scene_destroy(mi355rt_scene *scene);
+/* Frames in flight.  Camera.createImage() (Camera.java:119-185) renders one frame and waits for it; a caller that
+ * renders a sequence (the GUI's re-render on every settings change, a turntable, the tiles of consecutive frames on
+ * every GPU of a node) can have frame k + 1 on the chip while frame k ends on its longest rays and leaves the chip
+ * half empty.  A view is a second frame context on the same scene: it shares everything a frame only reads (hierarchy,
+ * faces, normals, BRDF tables: no second copy in HBM, no second build) and owns what a frame writes (scratch queues,
+ * counters, statistics, timers), so mi355rt_render_device calls on different views with different streams overlap on
+ * the GPU.  A view is used wherever a scene is (camera_setup, render*, frame_stats, ...) and destroyed with
+ * mi355rt_scene_destroy, in any order (the arrays live until the scene and all its views are destroyed).  Set the
+ * BRDF tables before creating views.  Calls on ONE handle are still one at a time; creating and destroying views of
+ * one scene is not thread safe. */
+int mi355rt_scene_view(mi355rt_scene *scene, mi355rt_scene **view_out);
 
 /* Replaces BRDFMaterial.brdfDirections / brdfWeights (materials/BRDFMaterial.java:33,43): takes the
  * PARSED tables (rows of table.txt: theta_v phi_v theta_i phi_i; rows of abrdf.dat) and applies

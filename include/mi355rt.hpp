@@ -299,6 +299,20 @@ class Scene {
    mi355rt_scene *handle_ = nullptr;
 };
 
+// mi355rt_scene_view: a second frame context on a scene (shared arrays in HBM, own scratch), for frames in flight.
+// Its handle is used wherever a scene's is.
+class SceneView {
+ public:
+   explicit SceneView(const Scene &scene) { check(mi355rt_scene_view(scene.handle(), &handle_)); }
+   SceneView(const SceneView &) = delete;
+   SceneView &operator=(const SceneView &) = delete;
+   ~SceneView() { mi355rt_scene_destroy(handle_); }
+   mi355rt_scene *handle() const { return handle_; }
+
+ private:
+   mi355rt_scene *handle_ = nullptr;
+};
+
 // Camera.java:25-215
 class Camera {
  public:

@@ -193,6 +193,11 @@ struct mi355rt_scene {
    int32_t *d_hit_obj = nullptr;
    float *d_hit_w = nullptr;
    size_t frame_pixels = 0;
+   // mi355rt_scene_view: a view shares the scene arrays of `parent` (everything a frame only reads) and owns what a frame
+   // writes (scratch, counters, read-back block, statistics, timers, host-render frame buffers)
+   mi355rt_scene *parent = nullptr;
+   int n_views = 0;      // views alive on this scene
+   bool dying = false;   // destroyed while views were alive: released with the last of them
 };
 
 namespace {
@@ -209,15 +214,21 @@ void free_scratch(FrameScratch &fs)
 void release_scene_impl(mi355rt_scene *s)
 {
    if (!s) return;
-   if (s->d_nodes) (void) hipFree(s->d_nodes);
-   if (s->d_descs) (void) hipFree(s->d_descs);
-   if (s->d_gfaces) (void) hipFree(s->d_gfaces);
-   if (s->d_slot_ids) (void) hipFree(s->d_slot_ids);
-   if (s->d_fnrm) (void) hipFree(s->d_fnrm);
-   if (s->d_objs) (void) hipFree(s->d_objs);
-   if (s->d_ext) (void) hipFree(s->d_ext);
-   if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
-   if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
+   if (!s->parent && s->n_views > 0) {   // its views still read the arrays: the last of them releases the scene
+      s->dying = true;
+      return;
+   }
+   if (!s->parent) {
+      if (s->d_nodes) (void) hipFree(s->d_nodes);
+      if (s->d_descs) (void) hipFree(s->d_descs);
+      if (s->d_gfaces) (void) hipFree(s->d_gfaces);
+      if (s->d_slot_ids) (void) hipFree(s->d_slot_ids);
+      if (s->d_fnrm) (void) hipFree(s->d_fnrm);
+      if (s->d_objs) (void) hipFree(s->d_objs);
+      if (s->d_ext) (void) hipFree(s->d_ext);
+      if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
+      if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
+   }
    if (s->d_counters) (void) hipFree(s->d_counters);
    if (s->h_readback) (void) hipHostFree(s->h_readback);
    if (s->d_rgb) (void) hipFree(s->d_rgb);
@@ -230,7 +241,9 @@ void release_scene_impl(mi355rt_scene *s)
       (void) hipEventDestroy(t.end);
    }
    for (hipEvent_t e : s->event_pool) (void) hipEventDestroy(e);
+   mi355rt_scene *root = s->parent;
    delete s;
+   if (root && --root->n_views == 0 && root->dying) release_scene_impl(root);
 }
 
 // waits for the pending timed launches and folds their durations into kernel_ms / kernel_launches
@@ -1024,10 +1037,54 @@ void mi355rt_scene_destroy(mi355rt_scene *scene)
    release_scene_impl(scene);
 }
 
+int mi355rt_scene_view(mi355rt_scene *scene, mi355rt_scene **view_out)
+{
+   return guarded([&]() -> int {
+      if (!scene || !view_out) return fail(MI355RT_E_ARG, "null argument");
+      *view_out = nullptr;
+      mi355rt_scene *root = scene->parent ? scene->parent : scene;
+      if (root->dying) return fail(MI355RT_E_ARG, "the scene has been destroyed");
+      DeviceScope scope(root->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      mi355rt_scene *v = new mi355rt_scene(*root);   // the array pointers, sizes, objects, bounds and flags
+      v->parent = root;
+      v->n_views = 0;
+      v->dying = false;
+      v->d_counters = nullptr;
+      v->h_readback = nullptr;
+      v->scratch = FrameScratch();
+      v->pending_times.clear();
+      v->event_pool.clear();
+      for (int k = 0; k < MI355RT_N_KERNELS; k++) {
+         v->kernel_ms[k] = 0.0;
+         v->kernel_launches[k] = 0;
+      }
+      v->stats_valid = false;
+      v->stats_accum = mi355rt_stats {};
+      v->d_rgb = nullptr;
+      v->d_hit_id = v->d_hit_obj = nullptr;
+      v->d_hit_w = nullptr;
+      v->frame_pixels = 0;
+      v->device_bytes = 0;   // what the view itself holds
+      root->n_views++;       // from here on release_scene_impl(v) undoes everything
+      hipError_t e = hipMalloc((void **) &v->d_counters, CNT_WORDS * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipHostMalloc((void **) &v->h_readback, N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
+      if (e == hipSuccess) e = hipMemset(v->d_counters, 0, CNT_WORDS * sizeof(uint32_t));
+      if (e != hipSuccess) {
+         release_scene_impl(v);
+         return hip_fail(e, "scene view");
+      }
+      v->device_bytes += CNT_WORDS * sizeof(uint32_t);
+      *view_out = v;
+      return MI355RT_OK;
+   });
+}
+
 int mi355rt_brdf_tables(mi355rt_scene *scene, const float *angles, int32_t n_dirs, const float *weights, int32_t n_materials)
 {
    return guarded([&]() -> int {
       if (!scene || !angles || !weights) return fail(MI355RT_E_ARG, "null argument");
+      if (scene->parent || scene->n_views > 0) return fail(MI355RT_E_ARG, "set the BRDF tables on the scene before creating views of it");
       if (n_dirs < 1 || n_materials < 1) return fail(MI355RT_E_ARG, "table sizes must be positive");
       DeviceScope scope(scene->device);
       if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");

@@ -338,6 +338,17 @@ class Scene:
         _abi.check(self._lib.mi355rt_scene_epsilon(self._handle, C.byref(eps)))
         RTStatics.EPSILON = float(eps.value)
 
+    def view(self):
+        """mi355rt_scene_view: a second frame context on this scene (shared arrays in HBM, own scratch), so that frames
+        rendered through different views on different streams are in flight together.  Cameras are made on a view
+        exactly as on a scene."""
+        v = object.__new__(Scene)
+        v.objects, v.light, v.cameraOrientation, v.lightingModel, v.fov = self.objects, self.light, self.cameraOrientation, self.lightingModel, self.fov
+        v._lib = self._lib
+        v._handle = C.c_void_p()
+        _abi.check(self._lib.mi355rt_scene_view(self._handle, C.byref(v._handle)))
+        return v
+
     def object_info(self, k):
         mm = (C.c_float * 6)()
         sd = C.c_float()

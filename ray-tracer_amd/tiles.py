@@ -148,3 +148,59 @@ class TileSharder:
                                                                  self.height, C.byref(fr), C.c_void_p(stream) if stream else None))
         else:
             tiles_unpack_reference(blocks, self.world, self.slots, self.tile, rgb, hit_id, hit_obj, hit_w)
+
+
+class FramePipeline:
+    """Frames in flight on one rank (mi355rt_scene_view).  Every launch of a frame ends on its longest rays
+    with the chip draining, and with N ranks each frame ends in an exchange; a sequence of frames hides both: `depth`
+    views of ONE scene (shared arrays in HBM, own scratch) on `depth` streams, round robin and without host
+    synchronisation, so frame k + 1 renders while frame k drains, and with N > 1 the gather of frame k's compact block
+    runs under it (rank 0 unpacks it when its slot comes round again, or at drain()).
+
+    make_camera(scene_or_view) -> host.Camera; slot b's outputs are `outs[b]` = [rgb, hit_id, hit_obj, hit_w] device
+    tensors in image order (on rank 0, or with world == 1)."""
+
+    def __init__(self, scene, make_camera, width, height, rank=0, world=1, depth=2, tile=DEFAULT_TILE, device="cuda", tile_world=None):
+        self.rank, self.world, self.depth, self.tile = rank, world, depth, tile
+        self.tile_world = world if tile_world is None else tile_world   # (tile_world != world: one rank's share of a larger run, for measurements)
+        self.device = torch.device(device)
+        self.views = [scene.view() for _ in range(depth)]
+        self.cams = [make_camera(v) for v in self.views]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        self.sharder = TileSharder(width, height, rank, world, tile, self.device, n_buffers=depth)
+        full = rank == 0 or world == 1
+        self.outs = [[torch.zeros((height, width, 3), dtype=torch.float32, device=self.device),
+                      torch.zeros((height, width), dtype=torch.int32, device=self.device),
+                      torch.zeros((height, width), dtype=torch.int32, device=self.device),
+                      torch.zeros((height, width), dtype=torch.float32, device=self.device)] if full else [None] * 4 for _ in range(depth)]
+        self.frames = [_abi.Frame(o[0].data_ptr(), None, o[1].data_ptr(), o[2].data_ptr(), o[3].data_ptr()) if world == 1
+                       else self.sharder.blocks[b].frame() for b, o in enumerate(self.outs)]
+        self._pending = [None] * depth
+        self._k = 0
+
+    def submit(self):
+        """Queues the next frame; returns its slot.  The slot's previous frame is finished first (stream-side)."""
+        b = self._k % self.depth
+        self._k += 1
+        with torch.cuda.stream(self.streams[b]):
+            if self._pending[b]:
+                self._pending[b]()
+            self.cams[b].render_device(self.frames[b], stream=self.streams[b].cuda_stream, tile_rank=self.rank, tile_world=self.tile_world,
+                                       tile_size=self.tile, tile_compact=self.world > 1)
+            self._pending[b] = self.sharder.gather(*self.outs[b], buffer=b, async_op=True) if self.world > 1 else None
+        return b
+
+    def drain(self):
+        """Finishes every frame in flight (their exchanges included) and waits for the device."""
+        for b in range(self.depth):
+            if self._pending[b]:
+                with torch.cuda.stream(self.streams[b]):
+                    self._pending[b]()
+                self._pending[b] = None
+        torch.cuda.synchronize(self.device)
+
+    def close(self):
+        self.drain()
+        for v in self.views:
+            v.close()
+        self.views = []
