@@ -322,8 +322,14 @@ int mi355rt_debug_arith(uint64_t n, const float *a, const float *b, float *out_d
  * (trace_kernels.hip ST_*).  No counterpart in the reference. */
 int mi355rt_debug_counters(mi355rt_scene *scene, uint64_t out[64]);
 
-/* Diagnostic: FNV-1a digests of the scene's three device arrays as uploaded -- out[0] node records, out[1] leaf
- * slots, out[2] face normals -- and out[3] = 1 if any mesh's hierarchy was built on the GPU.  The tests use it to
+/* Diagnostic: sizes of the scene's device arrays -- out[0] node records, [1] leaf descriptors,
+ * [2] group faces, [3] leaf slots (the reference's duplicated leaf entries), [4] leaf groups, [5] groups shared by
+ * several leaves, [6] 1 if the walker takes its form for leaves of tens of faces, [7] bytes resident on the device.
+ * No counterpart in the reference. */
+int mi355rt_debug_scene_layout(mi355rt_scene *scene, uint64_t out[8]);
+
+/* Diagnostic: FNV-1a digests of the scene's device arrays as uploaded -- out[0] node records, out[1] leaf data
+ * (descriptors, group faces, slot ids), out[2] face normals -- and out[3] = 1 if any mesh's hierarchy was built on the GPU.  The tests use it to
  * show that the GPU builder and the host builder (environment MI355RT_BUILDER=host) produce the same bytes.
  * No counterpart in the reference. */
 int mi355rt_debug_scene_digest(mi355rt_scene *scene, uint64_t out[4]);

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "mi355rt_scene_create_objects": (C.c_int, [C.POINTER(ObjectDesc), C.c_uint32, C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
     "mi355rt_scene_destroy": (None, [C.c_void_p]),
     "mi355rt_scene_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mi355rt_debug_scene_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mi355rt_brdf_tables": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_float_p, C.c_int32]),
     "mi355rt_scene_epsilon": (C.c_int, [C.c_void_p, c_float_p]),
     "mi355rt_scene_object_info": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, c_float_p, C.POINTER(C.c_uint64),

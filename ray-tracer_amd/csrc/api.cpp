@@ -1080,6 +1080,22 @@ int mi355rt_scene_view(mi355rt_scene *scene, mi355rt_scene **view_out)
    });
 }
 
+int mi355rt_debug_scene_layout(mi355rt_scene *scene, uint64_t out[8])
+{
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      out[0] = scene->n_node_recs;
+      out[1] = scene->n_descs;
+      out[2] = scene->n_gface_floats / 12;
+      out[3] = scene->n_slots;
+      out[4] = scene->n_groups;
+      out[5] = scene->n_shared_groups;
+      out[6] = scene->big_leaves ? 1 : 0;
+      out[7] = (scene->parent ? scene->parent : scene)->device_bytes;
+      return MI355RT_OK;
+   });
+}
+
 int mi355rt_brdf_tables(mi355rt_scene *scene, const float *angles, int32_t n_dirs, const float *weights, int32_t n_materials)
 {
    return guarded([&]() -> int {

@@ -1664,11 +1664,8 @@ bool big_leaves(const SceneArgs &sc)
 // MI355RT_WALKER=lds: the work-list walker (walk_lds.hip) instead of the lane walker below
 bool use_lds_walker()
 {
-   static const bool on = [] {
-      const char *v = getenv("MI355RT_WALKER");
-      return v && v[0] == 'l';
-   }();
-   return on;
+   const char *v = getenv("MI355RT_WALKER");   // read per launch: the tests switch it between frames
+   return v && v[0] == 'l';
 }
 
 template <int MODE>

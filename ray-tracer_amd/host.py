@@ -359,6 +359,13 @@ class Scene:
         return {"minmax": np.array(mm[:], dtype=np.float32), "shadow_distance": np.float32(sd.value),
                 "n_nodes": nn.value, "n_leaves": nl.value, "n_leaf_slots": ns.value, "max_depth": md.value}
 
+    def layout(self):
+        """mi355rt_debug_scene_layout: sizes of the device arrays."""
+        out = (C.c_uint64 * 8)()
+        _abi.check(self._lib.mi355rt_debug_scene_layout(self._handle, out))
+        return dict(zip(("node_records", "leaf_descriptors", "group_faces", "leaf_slots", "groups", "shared_groups", "big_leaves", "device_bytes"),
+                        [int(x) for x in out]))
+
     def digest(self):
         """mi355rt_debug_scene_digest: (nodes, leaf slots, normals) digests and whether any mesh was built on the GPU."""
         out = (C.c_uint64 * 4)()
