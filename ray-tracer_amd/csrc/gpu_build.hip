@@ -13,7 +13,7 @@
 //             order-preserving integer keys (min and max do not depend on the order); entries of nodes that do
 //             not split are parked in the leaf store
 //   finally   subtree sizes bottom-up, DFS pre-order numbers and first-slot numbers top-down, then one kernel writes
-//             the 64-byte node records and one the 48-byte leaf slots, in the layout of layout.h.
+//             the node records and one the leaf slots' face ids, in the layout of layout.h (the leaf groups follow on the host: scene_build.hpp).
 //
 // Every float that ends up in a record is produced by the same operation as on the host ((hi - lo) / 2 + lo for the
 // plane, min / max for the boxes), so the arrays are byte-identical to the host builder's (tests/test_gpu_build.py

@@ -1,7 +1,7 @@
 // layout.h -- HBM data layout shared by the host side and the HIP kernels of libmi355rt.
 //
 // SCENE (read-only during a frame).  One mesh object (= one KDTree of the reference,
-// bounds/KDTree.java) is three arrays (NodeRec is the host builder's form, DevNodeRec what is uploaded):
+// bounds/KDTree.java) is five arrays (NodeRec is the host builder's form, DevNodeRec what is uploaded):
 //
 // All objects' records are concatenated (links absolute); DevObject gives each object's root.
 //   nodes : one 80-byte record per INTERNAL node of the reference hierarchy, in DFS pre-order.

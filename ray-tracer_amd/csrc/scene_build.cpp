@@ -10,7 +10,7 @@
 //   * the root box covers ALL vertices, referenced or not (bounds/KDTree.java:35-44), and
 //     shadowDistance = max span / 2000 (KDTree.java:46).
 // What is different: the tree is never materialised as linked nodes.  Per-face bounds are computed
-// once; each internal node becomes one 64-byte record holding both children's boxes, emitted in
+// once; each internal node becomes one record holding both children's boxes (80 bytes on the device), emitted in
 // DFS pre-order, and leaf faces are appended to one slot array in DFS order.
 #include "scene_build.hpp"
 

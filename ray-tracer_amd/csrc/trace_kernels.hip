@@ -1038,6 +1038,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
             ps.fB = t[1];
             ps.fC = t[2];
          };
+         unsigned res = 0u;     // per leaf lane: the faces of its chunk that passed
+         bool served = false;   // its chunk was in one of this trip's passes
          auto test_pass = [&](const Pass &pc) {
             const int from = pc.src >= 0 ? pc.src : lane;
             Ray sr;
@@ -1046,23 +1048,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
             sr.inv = sr.d;   // not used by the triangle tests
             const bool met = pc.have && tri_meets(pc.fA, pc.fB, pc.fC, sr, eps);
             const unsigned long long bal = __ballot(met);
-            if (pc.my_base >= 0) {
-               const unsigned passed = (unsigned) (bal >> pc.my_base) & todo;   // (the lanes above this chunk's belong to the next one)
-               if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += (unsigned) __popc(todo);
-               missed |= todo & ~passed;
-               if (passed != 0u) {
-                  if (pend < 0) {
-                     const unsigned first = passed & (0u - passed);
-                     pend = ((gb & DESC_BASE_MASK) + __ffs((int) first) - 1) | (gb & DESC_IDENT);
-                     s_pkey[threadIdx.x] = ~cur;
-                     todo = passed & ~first;
-                  } else {
-                     todo = passed;   // one waits already: it is worked out first
-                  }
-                  want_resolve = todo != 0u || (FUSED && st.shadow);   // faces that could not be noted, or a shadow ray's first face
-               } else {
-                  todo = 0u;
-               }
+            if (pc.my_base >= 0) {   // (the lanes above this chunk's belong to the next one; what follows from the answer waits for the end of the burst)
+               res = (unsigned) (bal >> pc.my_base) & todo;
+               served = true;
             }
          };
          if (el != 0ull) {
@@ -1077,6 +1065,24 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                if (more) next_pass(p0);
                test_pass(p1);
                if (!more) break;
+            }
+         }
+         if (served) {
+            const unsigned passed = res;
+            if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += (unsigned) __popc(todo);
+            missed |= todo & ~passed;
+            if (passed != 0u) {
+               if (pend < 0) {
+                  const unsigned first = passed & (0u - passed);
+                  pend = ((gb & DESC_BASE_MASK) + __ffs((int) first) - 1) | (gb & DESC_IDENT);
+                  s_pkey[threadIdx.x] = ~cur;
+                  todo = passed & ~first;
+               } else {
+                  todo = passed;   // one waits already: it is worked out first
+               }
+               want_resolve = todo != 0u || (FUSED && st.shadow);   // faces that could not be noted, or a shadow ray's first face
+            } else {
+               todo = 0u;
             }
          }
          if (is_leaf && todo == 0u) {   // this chunk is finished: the leaf's next one, or back to the stack
