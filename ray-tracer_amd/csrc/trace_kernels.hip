@@ -149,10 +149,41 @@ __device__ __forceinline__ void remap_vectors(V3 normal, V3 tangent, V3 in_dir, 
    res[2] = cosi * coso;
 }
 
-// BRDFMaterial.getBRDFLuminocity materials/BRDFMaterial.java:53-92
+// One pass over the table of remapped directions: visit(j, PBRTMath.getDistance2 of entry j) in table order.  Two
+// entries per step in packed f32 (the same operations per entry, taken in the same order).
+template <typename F> __device__ __forceinline__ void brdf_scan(const float *__restrict__ dirs, int n_dirs, const float rm[3], F &&visit)
+{
+   int j = 0;
+   for (; j + 1 < n_dirs; j += 2) {
+      const f2 d0 = rm[0] - f2 { dirs[3 * j], dirs[3 * j + 3] }, d1 = rm[1] - f2 { dirs[3 * j + 1], dirs[3 * j + 4] };
+      const f2 d2 = rm[2] - f2 { dirs[3 * j + 2], dirs[3 * j + 5] };
+      const f2 sum = d0 * d0 + d1 * d1 + d2 * d2;
+      visit(j, fabsf(sum.x));
+      visit(j + 1, fabsf(sum.y));
+   }
+   for (; j < n_dirs; j++) {
+      const float d0 = rm[0] - dirs[3 * j], d1 = rm[1] - dirs[3 * j + 1], d2 = rm[2] - dirs[3 * j + 2];
+      visit(j, fabsf(d0 * d0 + d1 * d1 + d2 * d2));
+   }
+}
+
+// BRDFMaterial.getBRDFLuminocity materials/BRDFMaterial.java:53-92.
+// The reference rescans the whole table with a doubled radius (0.001, 0.002, ... below 1.5: eleven scans) until four
+// entries -- counted again in every later pass -- have been inside it, adding weight * exp(-100 d) per entry and pass in
+// (pass, table) order.  On the measured tables most of those scans find nothing, and the ones that do find a handful.
+// The same sum in the same order from three scans: (1) the nearest entry's distance: passes whose radius does not reach
+// it find nothing and change nothing; R = the first radius that does; (2) how many entries lie inside R, 2R, 4R, 8R: from R
+// on every pass counts at least the nearest entry again, so the loop ends within four passes, and the counts say after
+// which one (P); (3) the entries inside the last radius, in table order, into a short per-lane list -- the passes are then
+// replayed over that list.  A lane whose list would not fit runs the reference's scans for its passes instead.
+constexpr int BRDF_LIST = 16;
 __device__ float brdf_luminocity(const float *__restrict__ dirs, const float *__restrict__ weights, int n_dirs, int brdf_samples,
                                  V3 ray_dir, V3 point, V3 normal, V3 light)
 {
+   __shared__ int s_bj[BRDF_LIST * BLOCK_THREADS];
+   __shared__ float s_bd[BRDF_LIST * BLOCK_THREADS];
+   int *bj = s_bj + threadIdx.x;
+   float *bd = s_bd + threadIdx.x;
    float luminocity = 0.0f, weight = 0.0f;
    int ctr = 0;
    const V3 neg_ray = normalize3(scale3(ray_dir, -1.0f));
@@ -164,39 +195,72 @@ __device__ float brdf_luminocity(const float *__restrict__ dirs, const float *__
    for (int i = 0; i < brdf_samples; i++) {
       float rm[3];
       remap_vectors(normal, tangent, neg_ray, reflect3(normal, temp_dir), rm);
-      float last_max_dist2 = 0.001f;
-      while ((ctr < 4) && (last_max_dist2 < 1.5f)) {
-         // two table entries per step in packed f32 (the same operations per entry, taken in the same order)
-         int j = 0;
-         for (; j + 1 < n_dirs; j += 2) {
-            const f2 d0 = rm[0] - f2 { dirs[3 * j], dirs[3 * j + 3] }, d1 = rm[1] - f2 { dirs[3 * j + 1], dirs[3 * j + 4] };
-            const f2 d2 = rm[2] - f2 { dirs[3 * j + 2], dirs[3 * j + 5] };
-            const f2 sum = d0 * d0 + d1 * d1 + d2 * d2;
-            const float da = fabsf(sum.x), db = fabsf(sum.y);   // PBRTMath.getDistance2
-            if (da < last_max_dist2) {
-               const float temp = (float) exp(-100.0 * (double) da);
-               luminocity += weights[j] * temp;
-               weight += temp;
-               ctr++;
-            }
-            if (db < last_max_dist2) {
-               const float temp = (float) exp(-100.0 * (double) db);
-               luminocity += weights[j + 1] * temp;
-               weight += temp;
-               ctr++;
-            }
-         }
-         for (; j < n_dirs; j++) {
-            const float d0 = rm[0] - dirs[3 * j], d1 = rm[1] - dirs[3 * j + 1], d2 = rm[2] - dirs[3 * j + 2];
-            const float dist2 = fabsf(d0 * d0 + d1 * d1 + d2 * d2);   // PBRTMath.getDistance2
-            if (dist2 < last_max_dist2) {
-               const float temp = (float) exp(-100.0 * (double) dist2);
-               luminocity += weights[j] * temp;
-               weight += temp;
-               ctr++;
+      float nearest = __builtin_inff();   // (a NaN distance is inside no radius and is never the nearest)
+      brdf_scan(dirs, n_dirs, rm, [&](int, float d) {
+         if (d < nearest) nearest = d;
+      });
+      float R = 0.001f;   // the reference's radii, by its own doubling
+      while (!(nearest < R) && (R < 1.5f)) R *= 2.0f;
+      if (!(R < 1.5f)) continue;   // no pass of this sample finds an entry
+      const float R1 = R * 2.0f, R2 = R1 * 2.0f, R3 = R2 * 2.0f;
+      int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+      brdf_scan(dirs, n_dirs, rm, [&](int, float d) {
+         c0 += d < R ? 1 : 0;
+         c1 += d < R1 ? 1 : 0;
+         c2 += d < R2 ? 1 : 0;
+         c3 += d < R3 ? 1 : 0;
+      });
+      // the passes this sample runs: radius R, 2R, ... while ctr < 4 and the radius is below 1.5
+      int n_pass = 0, after = ctr, inside = 0;
+      {
+         float rad = R;
+         const int c[4] = { c0, c1, c2, c3 };
+#pragma unroll
+         for (int k = 0; k < 4; k++) {
+            if ((after < 4) && (rad < 1.5f)) {
+               after += c[k];
+               inside = c[k];
+               n_pass = k + 1;
+               rad *= 2.0f;
             }
          }
-         last_max_dist2 *= 2.0f;
+      }
+      const float r_last = n_pass == 1 ? R : (n_pass == 2 ? R1 : (n_pass == 3 ? R2 : R3));
+      if (inside <= BRDF_LIST) {
+         int n = 0;
+         brdf_scan(dirs, n_dirs, rm, [&](int j, float d) {
+            if (d < r_last) {
+               bj[n * BLOCK_THREADS] = j;
+               bd[n * BLOCK_THREADS] = d;
+               n++;
+            }
+         });
+         float rad = R;
+         for (int k = 0; k < n_pass; k++) {
+            for (int e = 0; e < n; e++) {
+               const float d = bd[e * BLOCK_THREADS];
+               if (d < rad) {
+                  const float temp = (float) exp(-100.0 * (double) d);
+                  luminocity += weights[bj[e * BLOCK_THREADS]] * temp;
+                  weight += temp;
+                  ctr++;
+               }
+            }
+            rad *= 2.0f;
+         }
+      } else {
+         float rad = R;
+         for (int k = 0; k < n_pass; k++) {
+            brdf_scan(dirs, n_dirs, rm, [&](int j, float d) {
+               if (d < rad) {
+                  const float temp = (float) exp(-100.0 * (double) d);
+                  luminocity += weights[j] * temp;
+                  weight += temp;
+                  ctr++;
+               }
+            });
+            rad *= 2.0f;
+         }
       }
       if (ctr >= 4) break;   // later samples would neither loop nor change anything
    }
