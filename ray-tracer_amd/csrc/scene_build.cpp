@@ -15,8 +15,10 @@
 #include "scene_build.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
+#include <thread>
 #include <utility>
 
 #include "host_math.hpp"
@@ -113,29 +115,39 @@ struct Links {
    int32_t llink, rlink, lcnt, rcnt;
 };
 
-class Grouper {
- public:
-   Grouper(void *records, size_t n_records, size_t stride, const int32_t *slot_face, GroupedLeaves &out)
-      : rec_((unsigned char *) records), stride_(stride), slot_face_(slot_face), out_(out)
-   {
-      range_.resize(n_records);
-   }
-
-   // slot range [begin, end) of every subtree (leaves are laid out in DFS order, so a subtree's slots are one run)
-   void ranges(int32_t link, int32_t cnt, int32_t &b, int32_t &e)
+// slot range [begin, end) of every subtree (leaves are laid out in DFS order, so a subtree's slots are one run)
+struct Ranges {
+   Ranges(const unsigned char *rec, size_t stride, size_t n_records) : rec_(rec), stride_(stride), range(n_records) {}
+   void find(int32_t link, int32_t cnt, int32_t &b, int32_t &e)
    {
       if (cnt > 0) {
          b = link;
          e = link + cnt;
          return;
       }
-      const Links r = *at(link);
+      const Links r = *(const Links *) (rec_ + stride_ * (size_t) link + 48);
       int32_t lb = -1, le = -1, rb = -1, re = -1;
-      if (r.llink != LINK_NONE) ranges(r.llink, r.lcnt, lb, le);
-      if (r.rlink != LINK_NONE) ranges(r.rlink, r.rcnt, rb, re);
+      if (r.llink != LINK_NONE) find(r.llink, r.lcnt, lb, le);
+      if (r.rlink != LINK_NONE) find(r.rlink, r.rcnt, rb, re);
       b = lb >= 0 ? lb : rb;
       e = re >= 0 ? re : le;
-      range_[(size_t) link] = { b, e };
+      range[(size_t) link] = { b, e };
+   }
+   const unsigned char *rec_;
+   size_t stride_;
+   std::vector<std::pair<int32_t, int32_t>> range;
+};
+
+// Groups the leaves of one subtree.  Run twice: `dry` (nothing is written: how many descriptors and group faces the
+// subtree makes), then for real with the places those counts give it in the object's arrays -- so that disjoint
+// subtrees can be done by different threads and the arrays still come out in DFS order.
+class Grouper {
+ public:
+   Grouper(void *records, size_t stride, const int32_t *slot_face, const Ranges &ranges, bool dry, LeafDesc *descs, int32_t *gface,
+           int32_t desc0, int32_t gface0)
+      : n_desc(desc0), n_gface(gface0), rec_((unsigned char *) records), stride_(stride), slot_face_(slot_face), range_(ranges.range), dry_(dry),
+        descs_(descs), gface_(gface)
+   {
    }
 
    // Walks the subtree under (link, cnt) in DFS order; returns the link the parent must store.
@@ -148,19 +160,29 @@ class Grouper {
          std::sort(ids_.begin(), ids_.end());
          ids_.erase(std::unique(ids_.begin(), ids_.end()), ids_.end());
          if ((int) ids_.size() <= GROUP_FACES) {
-            const int32_t gbase = (int32_t) out_.gface.size();
-            out_.gface.insert(out_.gface.end(), ids_.begin(), ids_.end());
-            out_.n_groups++;
-            out_.n_shared++;
+            const int32_t gbase = n_gface;
+            if (!dry_) std::copy(ids_.begin(), ids_.end(), gface_ + n_gface);
+            n_gface += (int32_t) ids_.size();
+            n_groups++;
+            n_shared++;
             in_group(link, gbase);
             return link;
          }
       }
       Links *r = at(link);
-      if (r->llink != LINK_NONE) r->llink = assign(r->llink, r->lcnt);
-      if (r->rlink != LINK_NONE) r->rlink = assign(r->rlink, r->rcnt);
+      if (r->llink != LINK_NONE) {
+         const int32_t l = assign(r->llink, r->lcnt);
+         if (!dry_) r->llink = l;
+      }
+      if (r->rlink != LINK_NONE) {
+         const int32_t l = assign(r->rlink, r->rcnt);
+         if (!dry_) r->rlink = l;
+      }
       return link;
    }
+
+   int32_t n_desc, n_gface;   // next free descriptor / group-face entry
+   uint64_t n_groups = 0, n_shared = 0;
 
  private:
    Links *at(int32_t node) const { return (Links *) (rec_ + stride_ * (size_t) node + 48); }
@@ -168,17 +190,21 @@ class Grouper {
    // a leaf that is its own group: GROUP_FACES faces per descriptor, in slot order
    int32_t leaf_alone(int32_t first_slot, int32_t cnt)
    {
-      const int32_t first_desc = (int32_t) out_.descs.size();
+      const int32_t first_desc = n_desc;
       for (int32_t done = 0; done < cnt; done += GROUP_FACES) {
          const int32_t n = std::min(GROUP_FACES, cnt - done);
-         LeafDesc d;
-         d.key = first_slot;
-         d.gbase = (int32_t) out_.gface.size() | DESC_IDENT | (done + n < cnt ? DESC_MORE : 0);
-         d.mask = n == 32 ? 0xffffffffu : ((1u << n) - 1u);
-         d.pad = 0;
-         out_.descs.push_back(d);
-         out_.gface.insert(out_.gface.end(), slot_face_ + first_slot + done, slot_face_ + first_slot + done + n);
-         out_.n_groups++;
+         if (!dry_) {
+            LeafDesc d;
+            d.key = first_slot;
+            d.gbase = n_gface | DESC_IDENT | (done + n < cnt ? DESC_MORE : 0);
+            d.mask = n == 32 ? 0xffffffffu : ((1u << n) - 1u);
+            d.pad = 0;
+            descs_[n_desc] = d;
+            std::copy(slot_face_ + first_slot + done, slot_face_ + first_slot + done + n, gface_ + n_gface);
+         }
+         n_desc++;
+         n_gface += n;
+         n_groups++;
       }
       return first_desc;
    }
@@ -195,27 +221,74 @@ class Grouper {
             in_group(l, gbase);
             continue;
          }
-         LeafDesc d;
-         d.key = l;
-         d.gbase = gbase;
-         d.mask = 0;
-         d.pad = 0;
-         for (int32_t k = 0; k < c; k++) {
-            const int32_t f = slot_face_[(size_t) (l + k)];
-            d.mask |= 1u << (uint32_t) (std::lower_bound(ids_.begin(), ids_.end(), f) - ids_.begin());
+         if (!dry_) {
+            LeafDesc d;
+            d.key = l;
+            d.gbase = gbase;
+            d.mask = 0;
+            d.pad = 0;
+            for (int32_t k = 0; k < c; k++) {
+               const int32_t f = slot_face_[(size_t) (l + k)];
+               d.mask |= 1u << (uint32_t) (std::lower_bound(ids_.begin(), ids_.end(), f) - ids_.begin());
+            }
+            descs_[n_desc] = d;
+            l = n_desc;
          }
-         l = (int32_t) out_.descs.size();
-         out_.descs.push_back(d);
+         n_desc++;
       }
    }
 
    unsigned char *rec_;
    size_t stride_;
    const int32_t *slot_face_;
-   GroupedLeaves &out_;
-   std::vector<std::pair<int32_t, int32_t>> range_;
+   const std::vector<std::pair<int32_t, int32_t>> &range_;
+   bool dry_;
+   LeafDesc *descs_;
+   int32_t *gface_;
    std::vector<int32_t> ids_;
 };
+
+// a subtree small enough to be one thread's piece of work, and where its (possibly rewritten) link goes
+struct GroupTask {
+   int32_t link, cnt;
+   int32_t *parent_slot;
+   int32_t n_desc = 0, n_gface = 0;
+   uint64_t n_groups = 0, n_shared = 0;
+};
+
+void collect_tasks(unsigned char *rec, size_t stride, const Ranges &ranges, int32_t piece, int32_t link, int32_t cnt, int32_t *parent_slot,
+                   std::vector<GroupTask> &tasks)
+{
+   if (cnt > 0 || ranges.range[(size_t) link].second - ranges.range[(size_t) link].first <= piece) {
+      GroupTask t;
+      t.link = link;
+      t.cnt = cnt;
+      t.parent_slot = parent_slot;
+      tasks.push_back(t);
+      return;
+   }
+   Links *r = (Links *) (rec + stride * (size_t) link + 48);   // (more slots than a group may span: never a group itself)
+   if (r->llink != LINK_NONE) collect_tasks(rec, stride, ranges, piece, r->llink, r->lcnt, &r->llink, tasks);
+   if (r->rlink != LINK_NONE) collect_tasks(rec, stride, ranges, piece, r->rlink, r->rcnt, &r->rlink, tasks);
+}
+
+template <typename F> void run_tasks(size_t n, F &&body)
+{
+   const unsigned hw = std::thread::hardware_concurrency();
+   const size_t n_threads = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 4 + 1);
+   if (n_threads <= 1) {
+      for (size_t i = 0; i < n; i++) body(i);
+      return;
+   }
+   std::atomic<size_t> next(0);
+   std::vector<std::thread> pool;
+   auto work = [&]() {
+      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
+   };
+   for (size_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+   work();
+   for (std::thread &t : pool) t.join();
+}
 
 }   // namespace
 
@@ -224,10 +297,41 @@ void group_leaves(void *records, size_t n_records, size_t stride, const int32_t 
    static_assert(offsetof(NodeRec, llink) == 48 && offsetof(DevNodeRec, llink) == 48, "the grouper reads the links at byte 48 of a record");
    out = GroupedLeaves();
    if (root_cnt == 0 && n_records == 0) return;   // an empty mesh: no leaf at all
-   Grouper g(records, n_records, stride, slot_face, out);
-   int32_t b, e;
-   g.ranges(root_link, root_cnt, b, e);
-   root_link = g.assign(root_link, root_cnt);
+   unsigned char *rec = (unsigned char *) records;
+   Ranges ranges(rec, stride, n_records);
+   int32_t b = 0, e = 0;
+   ranges.find(root_link, root_cnt, b, e);
+   // Disjoint subtrees are grouped independently (a group never spans more than GROUP_SLOTS slots, so cutting the tree
+   // into pieces of at least that many changes nothing): a dry run per piece for its counts, a prefix sum for its place
+   // in the arrays, then the real run.  The pieces depend on the tree alone, not on the number of threads.
+   const int32_t piece = std::max<int32_t>(GROUP_SLOTS, (e - b) / 1024);
+   std::vector<GroupTask> tasks;
+   collect_tasks(rec, stride, ranges, piece, root_link, root_cnt, &root_link, tasks);
+   run_tasks(tasks.size(), [&](size_t i) {
+      GroupTask &t = tasks[i];
+      Grouper g(records, stride, slot_face, ranges, true, nullptr, nullptr, 0, 0);
+      (void) g.assign(t.link, t.cnt);
+      t.n_desc = g.n_desc;
+      t.n_gface = g.n_gface;
+   });
+   std::vector<int32_t> desc0(tasks.size() + 1, 0), gface0(tasks.size() + 1, 0);
+   for (size_t i = 0; i < tasks.size(); i++) {
+      desc0[i + 1] = desc0[i] + tasks[i].n_desc;
+      gface0[i + 1] = gface0[i] + tasks[i].n_gface;
+   }
+   out.descs.resize((size_t) desc0.back());
+   out.gface.resize((size_t) gface0.back());
+   run_tasks(tasks.size(), [&](size_t i) {
+      GroupTask &t = tasks[i];
+      Grouper g(records, stride, slot_face, ranges, false, out.descs.data(), out.gface.data(), desc0[i], gface0[i]);
+      *t.parent_slot = g.assign(t.link, t.cnt);
+      t.n_groups = g.n_groups;
+      t.n_shared = g.n_shared;
+   });
+   for (const GroupTask &t : tasks) {
+      out.n_groups += t.n_groups;
+      out.n_shared += t.n_shared;
+   }
 }
 
 void synthesise_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, float *out)
