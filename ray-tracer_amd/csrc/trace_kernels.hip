@@ -489,6 +489,15 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
    const int n_objs = a.sc.n_objs;
    const float abs_max = a.sc.scene_abs_max;
 
+   // A queue much shorter than the pass's samples promised (a statue that fills a tenth of a 4K frame) wants fewer waves:
+   // every wave in flight at the end is a ray started late (launch sizes: blocks_per_cu_for).
+   if (a.trim_unit != 0u) {
+      unsigned total = 0;
+      for (int b = 0; b < N_BANDS; b++) total += a.counters[a.count_index + b];
+      const unsigned per_cu = (total + a.trim_unit / 2u) / a.trim_unit;
+      const unsigned useful = (per_cu > a.trim_lo ? per_cu : a.trim_lo) * a.trim_step;
+      if (blockIdx.x >= useful) return;
+   }
    // wave-uniform
    const int home = (int) (blockIdx.x % (unsigned) N_BANDS);
    int attempt = 0;
@@ -1774,6 +1783,9 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.cursor_index = cursor_index;
    a.band_cap = band_cap;
    a.stats = stats;
+   a.trim_unit = tunable("MI355RT_BLOCKS_PER_CU", 0) > 0 || !tunable("MI355RT_TRIM", 1) ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) tunable("MI355RT_TRIM_PRIMARY_X2", 5) / 2u;   // 2.5 rays per lane
+   a.trim_step = (unsigned) n_cus;
+   a.trim_lo = 2u;
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, big_leaves(sc) ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD));
    if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
    return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
@@ -1831,6 +1843,9 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.cursor_index = cursor_index;
    a.band_cap = p.band_cap;
    a.stats = p.stats;
+   a.trim_unit = tunable("MI355RT_BLOCKS_PER_CU_SHADOW", 0) > 0 || !tunable("MI355RT_TRIM", 1) ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) tunable("MI355RT_TRIM_SHADOW_X2", big_leaves(p.sc) ? 3 : 12) / 2u;   // 6 rays per lane; 1.5 where a ray is hundreds of triangle tests (measured: Thai- and Lucy-class)
+   a.trim_step = (unsigned) n_cus;
+   a.trim_lo = 1u;
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, big_leaves(p.sc) ? WALK_BIG_WAVES_PER_SIMD : 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream, n_cus, max_items);

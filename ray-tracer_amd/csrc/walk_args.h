@@ -25,6 +25,9 @@ struct WalkArgs {
    int32_t count_index, cursor_index;   // first of N_BANDS counters / cursors
    uint32_t band_cap;                   // slots per band sub-queue
    int32_t stats;
+   // The host sizes the grid from the pass's samples (the queue's length is only known on the device); a workgroup
+   // beyond round(rays queued / trim_unit) x trim_step, at least trim_lo, leaves at once (0: no trimming).
+   uint32_t trim_unit, trim_step, trim_lo;
 };
 
 // walk_lds.hip: the same walks by the work-list kernel; mode = one of MODE_*, stats 0 / 1
