@@ -251,7 +251,7 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
  * records mi355rt_render_device keeps in buffers it allocates on demand -- is a static device array of
  * MI355RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.  The frame must fit
  * it as ONE pass: ceil(8x8 pixel groups / 8) * 8 * 64 * multi_samples sample slots at 104 bytes each (204 with a
- * ReflectionMaterial in the scene, 348 with a RefractionMaterial): 1,290,000 slots for a mesh-only scene, e.g.
+ * ReflectionMaterial in the scene, 348 with a RefractionMaterial): 1,288,000 slots for a mesh-only scene, e.g.
  * 1280x960 at 1 spp or 640x480 at 4 spp; anything larger fails with MI355RT_E_LIMIT and changes nothing.
  * settings.collect_stats must be 0.  Inputs and outputs are as for mi355rt_render_device (device pointers in `frame`,
  * asynchronous on hip_stream unless the scene has mirrors or refraction, whose bounce loop reads a queue size back).

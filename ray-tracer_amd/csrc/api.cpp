@@ -140,6 +140,7 @@ struct FrameScratch {
    bool with_mirror = false, with_refraction = false;
    float *refr_parent = nullptr, *refr_terms = nullptr;
    float *samples = nullptr, *rays0 = nullptr, *hits0 = nullptr, *mat0 = nullptr;
+   unsigned long long *queued = nullptr;
    int32_t *hit_obj0 = nullptr;
    uint32_t *shadow = nullptr;
    float *rays1[2] = { nullptr, nullptr };
@@ -204,7 +205,7 @@ namespace {
 
 void free_scratch(FrameScratch &fs)
 {
-   void *all[] = { fs.samples, fs.rays0, fs.hits0, fs.mat0, fs.hit_obj0, fs.shadow, fs.rays1[0], fs.rays1[1], fs.hits1, fs.hit_obj1,
+   void *all[] = { fs.queued, fs.samples, fs.rays0, fs.hits0, fs.mat0, fs.hit_obj0, fs.shadow, fs.rays1[0], fs.rays1[1], fs.hits1, fs.hit_obj1,
                    fs.refr_parent, fs.refr_terms };
    for (void *q : all)
       if (q) (void) hipFree(q);
@@ -513,6 +514,7 @@ int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_ref
       size_t bytes;
    };
    const Want wants[] = {
+      { (void **) &fs.queued, cap / 8 },
       { (void **) &fs.samples, cap * 16 },  { (void **) &fs.rays0, cap * 32 },    { (void **) &fs.hits0, cap * 32 },
       { (void **) &fs.mat0, cap * 16 },     { (void **) &fs.hit_obj0, cap * 4 },  { (void **) &fs.shadow, cap * 4 },
       { (void **) &fs.rays1[0], with_mirror ? cap * 32 : 0 }, { (void **) &fs.rays1[1], with_mirror ? cap * 32 : 0 },
@@ -663,6 +665,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
    }
    const FrameScratch &fs = fixed ? *fixed : s->scratch;
    p.samples = fs.samples;
+   p.queued = fs.queued;
    p.rays0 = fs.rays0;
    p.hits0 = fs.hits0;
    p.hit_obj0 = fs.hit_obj0;
@@ -1243,8 +1246,8 @@ int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *ca
       const bool with_mirror = scene->has_mirror || scene->has_refraction, with_refraction = scene->has_refraction;
       const unsigned long long slots = (unsigned long long) ((n_micro + N_BANDS - 1) / N_BANDS) * N_BANDS * 64ull * (unsigned long long) settings->multi_samples;
       const unsigned long long per_slot = 104ull + (with_mirror ? 100ull : 0ull) + (with_refraction ? 16ull * (1 + MAX_REFRACTION_TERMS) : 0ull);
-      constexpr unsigned long long HEAD = 4096, ALIGN_SLACK = 12 * 256;   // counters; each of up to 12 arrays starts on a 256-byte boundary
-      if (slots * per_slot + HEAD + ALIGN_SLACK > (unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES)
+      constexpr unsigned long long HEAD = 4096, ALIGN_SLACK = 13 * 256;   // counters; each of up to 13 arrays starts on a 256-byte boundary
+      if (slots * per_slot + slots / 8 + HEAD + ALIGN_SLACK > (unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES)
          return fail(MI355RT_E_LIMIT, "mi355rt_render_device_noalloc: " + std::to_string(slots) + " sample slots x " + std::to_string(per_slot) +
                                           " bytes exceed the static scratch of " + std::to_string((unsigned long long) MI355RT_NOALLOC_SCRATCH_BYTES) +
                                           " bytes; use mi355rt_render_device for this frame");
@@ -1259,6 +1262,7 @@ int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *ca
       fs.cap = (size_t) slots;
       fs.with_mirror = with_mirror;
       fs.with_refraction = with_refraction;
+      fs.queued = (unsigned long long *) carve(slots / 8);
       fs.samples = (float *) carve(slots * 16);
       fs.rays0 = (float *) carve(slots * 32);
       fs.hits0 = (float *) carve(slots * 32);

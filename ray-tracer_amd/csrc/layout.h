@@ -193,6 +193,7 @@ struct FrameArgs {
    uint32_t band_cap;   // slots per band sub-queue: ceil(groups in pass / N_BANDS) * 64 * multi_samples
    // scratch
    float *samples;      // float4[cap]
+   unsigned long long *queued;   // per wave of generate (64 sample slots): which of them became rays -- the others hold the ambient colour without it being stored
    float *rays0;        // 2 x float4[cap]   primary queue
    float *hits0;        // 2 x float4[cap]
    int32_t *hit_obj0;   // [cap]
