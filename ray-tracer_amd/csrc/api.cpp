@@ -564,6 +564,26 @@ bool shadow_any_hit_is_exact(const mi355rt_scene *s, const mi355rt_settings *st)
    return std::sqrt(dl2) > 1.01 * reach + 1e-6 * (double) s->abs_max;
 }
 
+// layout.h FrameArgs::FastDiv.  d >= 1.  For d not a power of two 2^s < d < 2^(s+1), so m = ceil(2^(32+s) / d) lies in
+// (2^31, 2^32); mulhi(n, m) >> s = floor(n m / 2^(32+s)) and n (m - 2^(32+s)/d) < n <= 2^31 < 2^(32+s)/d, which is what makes
+// the floor exact.
+FrameArgs::FastDiv fast_div_of(uint32_t d)
+{
+   FrameArgs::FastDiv f;
+   f.d = d;
+   f.pad = 0;
+   uint32_t s = 0;
+   while ((2u << s) <= d && s < 31) ++s;   // floor(log2 d)
+   f.s = s;
+   if ((d & (d - 1)) == 0) {
+      f.m = 0;
+   } else {
+      const unsigned long long two = 1ull << (32 + s);
+      f.m = (uint32_t) ((two + d - 1) / d);
+   }
+   return f;
+}
+
 int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi355rt_settings *st, FrameArgs &p, long long &n_micro)
 {
    if (!cam) return fail(MI355RT_E_ARG, "camera is null");
@@ -636,6 +656,10 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    const long long n_tiles = (long long) p.tiles_x * p.tiles_y;
    const long long owned = n_tiles > st->tile_rank ? (n_tiles - st->tile_rank + world - 1) / world : 0;
    p.micro_per_tile = (tile / 8) * (tile / 8);
+   p.div_ms = fast_div_of((uint32_t) st->multi_samples);
+   p.div_micro_per_tile = fast_div_of((uint32_t) p.micro_per_tile);
+   p.div_tiles_x = fast_div_of((uint32_t) p.tiles_x);
+   p.div_mpr = fast_div_of((uint32_t) (tile / 8));
    n_micro = owned * p.micro_per_tile;
    if (n_micro > 0x3fffffffLL) return fail(MI355RT_E_LIMIT, "too many 8x8 pixel groups");
    p.tile_compact = st->tile_compact != 0 ? 1 : 0;

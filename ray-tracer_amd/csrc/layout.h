@@ -188,6 +188,12 @@ struct FrameArgs {
    int32_t n_dirs, n_materials;
    // tiles: this pass covers 8x8 pixel groups [micro_begin, micro_end) of the rank's enumeration
    int32_t tile_size, tile_rank, tile_world, tiles_x, tiles_y, micro_per_tile;
+   // Division by the frame's few fixed divisors without the divide sequence (a 32-bit one is thirty-odd instructions, and
+   // the index arithmetic of generate / resolve is mostly that): n / d = mulhi(n, m) >> s for every n < 2^31, with
+   // m = ceil(2^(32+s) / d), s = floor(log2 d); a power of two is a shift (m == 0).  fast_div_of() in api.cpp.
+   struct FastDiv {
+      uint32_t m, s, d, pad;
+   } div_ms, div_micro_per_tile, div_tiles_x, div_mpr;   // multi_samples, micro_per_tile, tiles_x, tile_size / 8
    int32_t tile_compact;   // outputs in tile-compact order (settings.tile_compact)
    int32_t micro_begin, micro_end;
    uint32_t band_cap;   // slots per band sub-queue: ceil(groups in pass / N_BANDS) * 64 * multi_samples

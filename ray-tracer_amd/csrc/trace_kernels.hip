@@ -327,14 +327,23 @@ __device__ __forceinline__ void store_ray(float *rays, unsigned idx, V3 o, V3 d,
 // pixel of (micro-tile, lane); false when it falls off the image.  opix = where the pixel's outputs go: its place in the
 // image (y * width + x), or, with settings.tile_compact, in this rank's run of owned tiles (owned tile k, row-major
 // inside the tile): what the one exchange step of a multi-GPU frame sends as it is.
+// n / d and n % d for the frame's fixed divisors (layout.h FastDiv); 0 <= n < 2^31
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FrameArgs::FastDiv &f) { return f.m ? __umulhi(n, f.m) >> f.s : n >> f.s; }
+__device__ __forceinline__ void fast_divmod(unsigned n, const FrameArgs::FastDiv &f, int &q, int &r)
+{
+   const unsigned qq = fast_div(n, f);
+   q = (int) qq;
+   r = (int) (n - qq * f.d);
+}
+
 __device__ __forceinline__ bool micro_pixel(const FrameArgs &p, int micro, int lane, int &px, int &py, long long &opix)
 {
-   const int k = micro / p.micro_per_tile;
-   const int within = micro % p.micro_per_tile;
+   int k, within, tx, ty, wx, wy;
+   fast_divmod((unsigned) micro, p.div_micro_per_tile, k, within);
    const int tile = p.tile_rank + k * p.tile_world;
-   const int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-   const int mpr = p.tile_size / 8;
-   const int lx = (within % mpr) * 8 + (lane & 7), ly = (within / mpr) * 8 + (lane >> 3);
+   fast_divmod((unsigned) tile, p.div_tiles_x, ty, tx);
+   fast_divmod((unsigned) within, p.div_mpr, wy, wx);
+   const int lx = wx * 8 + (lane & 7), ly = wy * 8 + (lane >> 3);
    px = tx * p.tile_size + lx;
    py = ty * p.tile_size + ly;
    opix = p.tile_compact ? ((long long) k * p.tile_size + ly) * p.tile_size + lx : (long long) py * p.width + px;
@@ -363,9 +372,9 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
    const int n_micro = p.micro_end - p.micro_begin;
    const int per_band = (n_micro + N_BANDS - 1) / N_BANDS;
    const int band = (int) (blockIdx.x % (unsigned) N_BANDS);
-   const long long wave_in_band = (long long) (blockIdx.x / (unsigned) N_BANDS) * GEN_WAVES + (threadIdx.x >> 6);
-   const int unit = (int) (wave_in_band / ms);
-   const int j = (int) (wave_in_band % ms);
+   const unsigned wave_in_band = (blockIdx.x / (unsigned) N_BANDS) * GEN_WAVES + (threadIdx.x >> 6);   // < 2^31: launch_generate
+   int unit, j;
+   fast_divmod(wave_in_band, p.div_ms, unit, j);
    const int local_micro = band * per_band + unit;
    const bool wave_ok = unit < per_band && local_micro < n_micro;
    const unsigned slot = ((unsigned) local_micro * (unsigned) ms + (unsigned) j) * 64u + (unsigned) lane;
@@ -1422,11 +1431,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
       }
       if (LEVEL == 0) {
          const unsigned wave = slot >> 6;
-         const int j = (int) (wave % (unsigned) p.multi_samples);
+         int unit, j;
+         fast_divmod(wave, p.div_ms, unit, j);
          if (j == 0 && (p.hit_id || p.hit_obj || p.hit_w)) {
             int px, py;
             long long pix;
-            (void) micro_pixel(p, p.micro_begin + (int) (wave / (unsigned) p.multi_samples), (int) (slot & 63u), px, py, pix);
+            (void) micro_pixel(p, p.micro_begin + unit, (int) (slot & 63u), px, py, pix);
             if (obj < 0) {
                write_miss_outputs(p, pix);
             } else {
