@@ -18,6 +18,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstddef>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <utility>
 
@@ -272,6 +274,8 @@ void collect_tasks(unsigned char *rec, size_t stride, const Ranges &ranges, int3
    if (r->rlink != LINK_NONE) collect_tasks(rec, stride, ranges, piece, r->rlink, r->rcnt, &r->rlink, tasks);
 }
 
+// body(i) for i in [0, n) on up to 16 threads.  What a body throws (an allocation failure) is rethrown here, on the
+// caller's thread, after every worker has stopped: nothing may leave a worker thread.
 template <typename F> void run_tasks(size_t n, F &&body)
 {
    const unsigned hw = std::thread::hardware_concurrency();
@@ -281,13 +285,26 @@ template <typename F> void run_tasks(size_t n, F &&body)
       return;
    }
    std::atomic<size_t> next(0);
-   std::vector<std::thread> pool;
+   std::atomic<bool> failed(false);
+   std::exception_ptr error;
+   std::mutex error_lock;
    auto work = [&]() {
-      for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) body(i);
+      try {
+         for (size_t i = next.fetch_add(1); i < n && !failed.load(); i = next.fetch_add(1)) body(i);
+      } catch (...) {
+         std::lock_guard<std::mutex> hold(error_lock);
+         if (!error) error = std::current_exception();
+         failed.store(true);
+      }
    };
-   for (size_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+   std::vector<std::thread> pool;
+   try {
+      for (size_t t = 1; t < n_threads; t++) pool.emplace_back(work);
+   } catch (...) {   // no more threads to be had: the ones there are, and this one, do the work
+   }
    work();
    for (std::thread &t : pool) t.join();
+   if (error) std::rethrow_exception(error);
 }
 
 }   // namespace
