@@ -78,6 +78,9 @@ def parse_args():
     ap.add_argument("--frames-in-flight", type=int, default=2, help="the 'pipelined' figure: frames in flight per rank; 1 = skip")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="CPU rehearsal of the N-rank launch and exchange: gloo, library-shaped blocks, no GPU, no rendering")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="with --gpus N: all N ranks on GPU 0, blocks exchanged over gloo through host memory -- runs the whole N-rank code "
+                         "path (tile shares, compact blocks, gather, unpack, frames in flight, frame check) where there is one GPU; not a bench result")
     return ap.parse_args()
 
 
@@ -85,7 +88,7 @@ def launch_ranks(args):
     """The parent of an N-rank run.  It makes no torch.cuda / HIP call that initialises a GPU (device_count does not, on
     this image): a process that has touched the GPU must not be replaced or forked into rank processes."""
     n = args.gpus
-    if not args.dry_run_gloo:
+    if not args.dry_run_gloo and not args.rehearse_one_gpu:
         have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report a %d-GPU number from fewer GPUs\n"
@@ -97,7 +100,7 @@ def launch_ranks(args):
     procs = []
     rank0_out = tempfile.TemporaryFile(mode="w+")   # a file, not a pipe: nothing can block on a full pipe while the parent polls
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if args.rehearse_one_gpu else str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=rank0_out if r == 0 else sys.stderr))
@@ -211,8 +214,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rehearse = args.rehearse_one_gpu and world > 1
+    cdev = torch.device("cpu") if rehearse else dev   # where the few scalars that travel between ranks live
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
@@ -243,7 +251,7 @@ def main():
     hit_obj = torch.zeros((H, W), dtype=torch.int32, device=dev)
     hit_w = torch.zeros((H, W), dtype=torch.float32, device=dev)
     frame = rt._abi.Frame(rgb.data_ptr(), None, hit_id.data_ptr(), hit_obj.data_ptr(), hit_w.data_ptr())
-    sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev)
+    sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev, via_host=rehearse)
     stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream
 
     tile_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
@@ -262,7 +270,7 @@ def main():
     st = cam.frame_stats()
     kcounts = cam.kernel_profile(reset=True)   # per-walker counts of that frame
     counts = torch.tensor([st["primary_rays"], st["shadow_rays"], st["secondary_rays"], st["box_tests"], st["tri_tests"],
-                           st["hits"]], dtype=torch.float64, device=dev)
+                           st["hits"]], dtype=torch.float64, device=cdev)
     local_counts = counts.clone()
     if world > 1:
         dist.all_reduce(counts)
@@ -298,10 +306,10 @@ def main():
     kprof = cam.kernel_profile()
     rank_ms = [frame_ms]
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        mine = torch.tensor([frame_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([frame_ms], dtype=torch.float64, device=cdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         rank_ms = [float(t.item()) for t in every]
@@ -314,7 +322,7 @@ def main():
     pipelined = None
     if args.frames_in_flight > 1:
         try:
-            pipelined = frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame)
+            pipelined = frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame, rehearse)
         except Exception as e:   # the extra figure must not cost the run its headline line (N > 1: RCCL side streams are untested here)
             pipelined = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
@@ -424,6 +432,8 @@ def main():
         out["soup"] = soup
     if frame_verified is not None:
         out["gathered_frame_equals_single_gpu_frame"] = frame_verified
+    if rehearse:
+        out["rehearsal"] = "all %d ranks on one GPU, blocks exchanged over gloo through host memory: the N-rank code path, not a bench result" % world
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
     print(json.dumps(out))
@@ -441,14 +451,14 @@ def shadow_any_hit_proven(scene, light):
     return float(np.linalg.norm(d)) > 1.01 * diag
 
 
-def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame):
+def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame, via_host=False):
     """K frames with D in flight on every rank (tiles.FramePipeline): D views of the scene (mi355rt_scene_view: shared
     arrays, own scratch) on D streams, round robin, no host sync between; with N > 1 each frame's block is gathered
     asynchronously and unpacked on rank 0 when its slot comes round again, so the exchange of frame k runs under the
     render of frame k + 1."""
     D = args.frames_in_flight
     pipe = tiles.FramePipeline(scene, lambda sc: rt.Camera(sc, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024),
-                               W, H, rank, world, D, tiles.DEFAULT_TILE, dev, tile_world=tile_world)
+                               W, H, rank, world, D, tiles.DEFAULT_TILE, dev, tile_world=tile_world, via_host=via_host)
     full = rank == 0
     for _ in range(2 * D):
         pipe.submit()
@@ -464,7 +474,7 @@ def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H,
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=torch.device("cpu") if via_host else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     dt /= n

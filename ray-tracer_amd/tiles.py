@@ -103,8 +103,9 @@ class TileSharder:
     """The per-frame exchange of one rank.  `n_buffers` independent blocks let frames be in flight: frame k's block
     travels while frame k + 1 renders into another."""
 
-    def __init__(self, width, height, rank, world, tile=DEFAULT_TILE, device="cpu", n_buffers=1):
+    def __init__(self, width, height, rank, world, tile=DEFAULT_TILE, device="cpu", n_buffers=1, via_host=False):
         self.width, self.height, self.rank, self.world, self.tile = width, height, rank, world, tile
+        self.via_host = via_host   # rehearsals only (several ranks on ONE GPU over gloo): the blocks travel through host memory
         self.device = torch.device(device)
         self.slots = max_owned(width, height, world, tile)
         self.n = self.slots * tile * tile
@@ -122,7 +123,12 @@ class TileSharder:
         if self.world == 1:
             return (lambda: None) if async_op else None
         send = self.blocks[buffer].flat
-        if self.rank == 0:
+        staged = None
+        if self.via_host:
+            send = send.cpu()   # (waits for the stream that rendered into the block)
+            staged = [torch.empty_like(send) for _ in range(self.world)] if self.rank == 0 else None
+            work = dist.gather(send, gather_list=staged, dst=0, async_op=True)
+        elif self.rank == 0:
             recv = self.recv[buffer]
             work = dist.gather(send, gather_list=list(recv.view(self.world, -1).unbind(0)), dst=0, async_op=True)
         else:
@@ -131,6 +137,8 @@ class TileSharder:
         def finish():
             work.wait()   # on the GPU: the current stream waits for the collective; the host does not
             if self.rank == 0:
+                if staged is not None:
+                    self.recv[buffer].copy_(torch.cat(staged))
                 self.unpack(self.recv[buffer], rgb, hit_id, hit_obj, hit_w)
 
         if async_op:
@@ -160,14 +168,15 @@ class FramePipeline:
     make_camera(scene_or_view) -> host.Camera; slot b's outputs are `outs[b]` = [rgb, hit_id, hit_obj, hit_w] device
     tensors in image order (on rank 0, or with world == 1)."""
 
-    def __init__(self, scene, make_camera, width, height, rank=0, world=1, depth=2, tile=DEFAULT_TILE, device="cuda", tile_world=None):
+    def __init__(self, scene, make_camera, width, height, rank=0, world=1, depth=2, tile=DEFAULT_TILE, device="cuda", tile_world=None,
+                 via_host=False):
         self.rank, self.world, self.depth, self.tile = rank, world, depth, tile
         self.tile_world = world if tile_world is None else tile_world   # (tile_world != world: one rank's share of a larger run, for measurements)
         self.device = torch.device(device)
         self.views = [scene.view() for _ in range(depth)]
         self.cams = [make_camera(v) for v in self.views]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
-        self.sharder = TileSharder(width, height, rank, world, tile, self.device, n_buffers=depth)
+        self.sharder = TileSharder(width, height, rank, world, tile, self.device, n_buffers=depth, via_host=via_host)
         full = rank == 0 or world == 1
         self.outs = [[torch.zeros((height, width, 3), dtype=torch.float32, device=self.device),
                       torch.zeros((height, width), dtype=torch.int32, device=self.device),

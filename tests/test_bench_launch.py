@@ -47,3 +47,22 @@ def test_a_failing_rank_fails_the_run():
     r = _run("--gpus", 2, "--dry-run-gloo", "--width", 0, "--height", 0)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_n_rank_path_rehearsed_on_one_gpu():
+    """The whole N-rank bench path on the one GPU a test box has: 3 ranks share GPU 0 (tile shares rendered as compact blocks,
+    one gather -- over gloo through host memory here, RCCL on a node --, the library's unpack kernel, frames in flight on
+    scene views, and rank 0's check that the gathered frame is the single-GPU frame, bit for bit)."""
+    r = _run("--gpus", 3, "--rehearse-one-gpu", "--steps", 4, "--warmup", 1, "--no-cpu-baseline", "--width", 640, "--height", 360, "--faces", 60000)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["ranks"] == 3 and "rehearsal" in out
+    assert out["gathered_frame_equals_single_gpu_frame"] is True
+    assert out["pipelined"]["frames_identical"] is True
+    assert len(out["rank_render_ms"]["all"]) == 3
