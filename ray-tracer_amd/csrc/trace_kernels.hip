@@ -483,6 +483,12 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
 #endif
+#ifndef WALK_DUAL
+#define WALK_DUAL 0   // 1: a lane walks nodes and tests a leaf in the same trip (see "two sides" below)
+#endif
+#ifndef WALK_DUAL_MIN
+#define WALK_DUAL_MIN 12
+#endif
 constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip
 static_assert(LEAF_BATCH == 2, "a leaf trip fetches two faces");
 
@@ -531,6 +537,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
    constexpr bool CLOSEST = MODE == MODE_CLOSEST || MODE == MODE_FUSED;   // rays come from the queue; faces wait in `pend`
    constexpr bool FUSED = MODE == MODE_FUSED;
    constexpr bool DEFER = CLOSEST || BIG != 0;   // faces that pass the triangle tests wait in `pend` for the resolve block
+   constexpr bool DUAL = BIG == 0 && WALK_DUAL != 0;
    // Thresholds, measured on the bench frame and its shares: they were launch arguments while they were being
    // tuned; as constants they cost no scalar registers (the kernel is short of them: it spills scalars into vector lanes).
    constexpr int REFILL_MIN = CLOSEST ? WALK_REFILL_MIN : 64;   // refill once this many lanes are idle (or all of them); shadow waves refill whole
@@ -556,6 +563,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
    st.redo = 0;
    float safe_w = 0.0f;   // MODE_SHADOW: an accepted face nearer than this ends the walk of its object (shadow_safe_w)
    int cur = STACK_EMPTY;
+   // Two sides (DUAL): the reference visits every leaf whose boxes the ray meets, so nothing obliges a lane to finish a leaf
+   // before it walks on.  `cur` is the node side (a node; a leaf waiting for the leaf side to come free; STACK_EMPTY with an
+   // empty stack), `lf` the leaf side (~descriptor of the leaf being tested, 0: none).  A trip runs a node step AND two
+   // faces of the leaf for such a lane; what the node side does ahead of a face that turns out to be hit is pruned when
+   // the answer is in, exactly as a stolen subtree's is.
+   int lf = 0;
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
    int pend = -1;         // MODE_CLOSEST: a face of the current object that passed the triangle tests and whose point and
@@ -591,6 +604,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
       }
       return false;
    };
+   auto over = [&]() -> bool { return cur == STACK_EMPTY && (!DUAL || lf == 0); };   // this lane's walk of its object (or subtree) has ended
    unsigned n_box = 0, n_tri = 0, n_hit = 0, n_ray = 0, n_spawn = 0;
    unsigned n_box_s = 0, n_tri_s = 0;   // MODE_FUSED: tests made for shadow rays
    unsigned d_ray_trips = 0, d_ray_trips_max = 0;
@@ -611,7 +625,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
       // fold does not depend on when it happens (see the tie rule), and slots of one leaf still arrive in slot order.
       if (DEFER) {
          const unsigned long long pm = __ballot(pend >= 0);
-         if (pm != 0ull && (resolve_req || exhausted || (int) __popcll(pm) >= RESOLVE_MIN || __ballot(pend >= 0 && cur == STACK_EMPTY) != 0ull)) {
+         if (pm != 0ull && (resolve_req || exhausted || (int) __popcll(pm) >= RESOLVE_MIN || __ballot(pend >= 0 && over()) != 0ull)) {
             const float sd = st.k >= 0 ? a.sc.objs[st.k].shadow_distance : 0.0f;
             if (pend >= 0) {
                const float4 *t = gfaces + 3 * (size_t) (pend & DESC_BASE_MASK);
@@ -630,6 +644,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                   if ((FUSED && st.shadow) || MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {
                      sp = bot;
                      cur = STACK_EMPTY;
+                     lf = 0;
                      todo = 0;
                   }
                }
@@ -641,12 +656,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
       // The bookkeeping below serves lanes whose walk has just ended.  One ends somewhere in the wave nearly every trip, and
       // the block is a hundred-odd instructions for the whole wave: ended lanes wait until admin_min of them do (or the
       // idle ones suffice for a refill, or nothing else is left to walk, or the queue is dry and every lane counts).
-      const unsigned long long ended = __ballot(cur == STACK_EMPTY);
-      const int n_serve = __popcll(__ballot(cur == STACK_EMPTY && st.role != ROLE_IDLE));
+      const unsigned long long ended = __ballot(over());
+      const int n_serve = __popcll(__ballot(over() && st.role != ROLE_IDLE));
       if (ended != 0ull && (exhausted || n_serve >= ADMIN_MIN || ended == ~0ull || (n_serve == 0 && (int) __popcll(ended) >= REFILL_MIN))) {
          // ---- (1) helpers that finished their subtree hand (w, slot, leaf) to the ray's owner, which
          // folds it in with the same order-independent rule the leaves use
-         unsigned long long fin = __ballot(st.role == ROLE_HELPER && cur == STACK_EMPTY);
+         unsigned long long fin = __ballot(st.role == ROLE_HELPER && over());
          while (fin != 0ull) {
             const int h = __ffsll((unsigned long long) fin) - 1;
             fin &= fin - 1ull;
@@ -664,14 +679,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                }
             }
          }
-         if (st.role == ROLE_HELPER && cur == STACK_EMPTY) {
+         if (st.role == ROLE_HELPER && over()) {
             st.role = ROLE_IDLE;
             st.owner = lane;
          }
 
          // ---- (2) an owner whose walk of object k has ended (and whose helpers are all back): fold the
          // object's result, enter the next object or retire the ray
-         if (st.role == ROLE_OWNER && cur == STACK_EMPTY && st.pending == 0) {
+         if (st.role == ROLE_OWNER && over() && st.pending == 0) {
             bool redo_k = false;
             if (st.k >= 0 && ob_gf >= 0) {
                if (CLOSEST && !(FUSED && st.shadow)) {
@@ -911,6 +926,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                st.plain = plain_ray(r) && a.sc.boxes_finite;
                age = v_age;
                cur = entry;
+               lf = 0;
                todo = 0;
                sp = bot = 0;
                ob_gf = -1;
@@ -935,6 +951,219 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
             if (exhausted) break;
             continue;
          }
+      }
+
+      if (DUAL) {
+         // ---- two sides: a node step for the lanes at a node, then two faces for the lanes that hold a leaf (a lane
+         // can be both).  Fetches are one after the other -- node records, then faces -- so that they share registers.
+         if (STATS > 1 && st.role == ROLE_OWNER) d_ray_trips++;
+         if (!CLOSEST) ++age;
+         if (lf == 0 && cur < 0) {   // the leaf side is free: the waiting leaf moves over (it came off the stack: its descriptor is read first)
+            lf = cur;
+            todo = 0u;
+            if (sp > bot) {
+               --sp;
+               cur = stack[sp * BLOCK_THREADS];
+            } else {
+               cur = STACK_EMPTY;
+            }
+         }
+         constexpr int SIDE_MIN = WALK_DUAL_MIN;   // a side with fewer lanes than this sits the trip out, unless the other does
+         const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
+         const int n_node = __popcll(__ballot(in_node)), n_leaf0 = __popcll(__ballot(lf < 0));
+         const bool run_node = n_node > 0 && (exhausted || n_node >= SIDE_MIN || n_node >= n_leaf0);
+         if (run_node) {
+            const float4 *pa = nodes + NODE_F4 * (size_t) (in_node ? cur : 0);
+            const float4 na = pa[0], nb = pa[1], nc = pa[2], q3 = pa[3], q4 = pa[4];
+            const int4 nd = make_int4(__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w));
+            if (in_node) {
+               if (STATS > 1) {
+                  d_node_lane++;
+                  if (first_active_lane()) d_node_wave++;
+               }
+               float tl = 0.0f, tr = 0.0f;
+               bool lok = false, rok = false;
+               if (STATS) (FUSED && st.shadow ? n_box_s : n_box) += (nd.x != LINK_NONE ? 1u : 0u) + (nd.y != LINK_NONE ? 1u : 0u);
+               if (st.plain) {   // (the packed form of the step below: same arithmetic, same argument)
+                  const f2 ax = f2 { na.x, na.y } - r.o.x, ay = f2 { na.z, na.w } - r.o.y, az = f2 { nb.x, nb.y } - r.o.z;
+                  const f2 bx = f2 { nb.z, nb.w } - r.o.x, by = f2 { nc.x, nc.y } - r.o.y, bz = f2 { nc.z, nc.w } - r.o.z;
+                  const f2 t1x = ax * r.inv.x, t1y = ay * r.inv.y, t1z = az * r.inv.z;
+                  const f2 t2x = bx * r.inv.x, t2y = by * r.inv.y, t2z = bz * r.inv.z;
+                  const f2 ddx = { fmaxf(fmaxf(ax.x, -bx.x), 0.0f), fmaxf(fmaxf(ax.y, -bx.y), 0.0f) };
+                  const f2 ddy = { fmaxf(fmaxf(ay.x, -by.x), 0.0f), fmaxf(fmaxf(ay.y, -by.y), 0.0f) };
+                  const f2 ddz = { fmaxf(fmaxf(az.x, -bz.x), 0.0f), fmaxf(fmaxf(az.y, -bz.y), 0.0f) };
+                  const f2 d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                  tl = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
+                  tr = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
+                  const float hl = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
+                  const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
+                  lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
+                  rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
+                  if (MODE == MODE_SHADOW && !st.redo) {
+                     const f2 fx = { fmaxf(light.x - na.x, nb.z - light.x), fmaxf(light.x - na.y, nb.w - light.x) };
+                     const f2 fy = { fmaxf(light.y - na.z, nc.x - light.y), fmaxf(light.y - na.w, nc.y - light.y) };
+                     const f2 fz = { fmaxf(light.z - nb.x, nc.z - light.z), fmaxf(light.z - nb.y, nc.w - light.z) };
+                     const f2 far2 = (fx * fx + fy * fy + fz * fz) * 1.0001f + a.light_prune_c;
+                     lok = lok && !(d2.x > far2.x);
+                     rok = rok && !(d2.y > far2.y);
+                  }
+               } else {
+                  if (nd.x != LINK_NONE)
+                     lok = slab_test(r, nearp, farp, na.x, na.z, nb.x, nb.z, nc.x, nc.z, tl) &&
+                           !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > lim2);
+                  if (nd.y != LINK_NONE)
+                     rok = slab_test(r, nearp, farp, na.y, na.w, nb.y, nb.w, nc.y, nc.w, tr) &&
+                           !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > lim2);
+                  if (MODE == MODE_SHADOW && !st.redo && a.sc.boxes_finite) {
+                     lok = lok && !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > light_far2(light, na.x, na.z, nb.x, nb.z, nc.x, nc.z) * 1.0001f + a.light_prune_c);
+                     rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
+                  }
+               }
+               const int le = nd.z > 0 ? ~nd.x : nd.x;
+               const int re = nd.w > 0 ? ~nd.y : nd.y;
+               // what is left to test in a leaf child is known here (the leaf side's group and `missed` only ever grow
+               // while the group stays: a face in `missed` HAS missed this ray, whenever that is asked)
+               const int lg = __float_as_int(q4.x), rg = __float_as_int(q4.z);
+               const unsigned ltodo = __float_as_uint(q4.y) & ~((((lg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
+               const unsigned rtodo = __float_as_uint(q4.w) & ~((((rg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
+               if (nd.z > 0 && ltodo == 0u && !(lg & DESC_MORE)) {
+                  if (STATS > 1 && lok) d_repeat += (unsigned) __popc(__float_as_uint(q4.y));
+                  lok = false;
+               }
+               if (nd.w > 0 && rtodo == 0u && !(rg & DESC_MORE)) {
+                  if (STATS > 1 && rok) d_repeat += (unsigned) __popc(__float_as_uint(q4.w));
+                  rok = false;
+               }
+               // A leaf child goes to the leaf side if that is free (with its words: no descriptor read); the node side
+               // goes on with the other child or the stack.  A leaf child that finds the leaf side busy waits in `cur`.
+               const bool lfree = lf == 0;
+               int hand = 0;   // 1 / 2: the left / right child goes to the leaf side
+               if (lok && rok) {
+                  const bool swap = tr < tl;   // nearest child first; the order never decides WHETHER a child is visited
+                  const int n1 = swap ? re : le, n2 = swap ? le : re;
+                  if (lfree && n1 < 0) {
+                     hand = swap ? 2 : 1;
+                     cur = n2;
+                  } else if (lfree && n2 < 0) {
+                     hand = swap ? 1 : 2;
+                     cur = n1;
+                  } else {
+                     cur = n1;
+                     stack[sp * BLOCK_THREADS] = n2;
+                     ++sp;
+                  }
+               } else if (lok || rok) {
+                  const int n1 = lok ? le : re;
+                  if (lfree && n1 < 0) {
+                     hand = lok ? 1 : 2;
+                     if (sp > bot) {
+                        --sp;
+                        cur = stack[sp * BLOCK_THREADS];
+                     } else {
+                        cur = STACK_EMPTY;
+                     }
+                  } else {
+                     cur = n1;
+                  }
+               } else if (sp > bot) {
+                  --sp;
+                  cur = stack[sp * BLOCK_THREADS];
+               } else {
+                  cur = STACK_EMPTY;
+               }
+               if (hand != 0) {
+                  const int g = hand == 1 ? lg : rg;
+                  lf = hand == 1 ? le : re;
+                  if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
+                  if (STATS > 1) d_repeat += (unsigned) __popc((hand == 1 ? __float_as_uint(q4.y) : __float_as_uint(q4.w)) & missed);
+                  gb = g;
+                  todo = hand == 1 ? ltodo : rtodo;   // 0 only for a leaf that goes on in further descriptors: the leaf step moves on
+               }
+            }
+         }
+         // the leaf side, with the leaves the node step has just handed over
+         bool want_resolve = false;
+         const bool in_leaf = lf < 0;
+         const int n_leaf = __popcll(__ballot(in_leaf));
+         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= SIDE_MIN || !run_node);
+         if (run_leaf) {
+            const bool want_desc = in_leaf && todo == 0u;
+            const unsigned rest0 = todo & (todo - 1u);
+            const size_t f0 = in_leaf && !want_desc ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) todo) - 1) : 0;
+            const size_t f1 = in_leaf && rest0 != 0u ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) rest0) - 1) : f0;
+            const float4 *pa = want_desc ? descs + (size_t) ~lf : gfaces + 3 * f0;
+            const float4 *pb = gfaces + 3 * f1;
+            float4 q[6];
+#pragma unroll
+            for (int j = 0; j < 3; j++) q[j] = pa[j];   // (a descriptor is one float4: the array is padded for the other two)
+#pragma unroll
+            for (int j = 0; j < 3; j++) q[3 + j] = pb[j];
+            if (in_leaf) {
+               if (STATS > 1) {
+                  d_leaf_lane++;
+                  if (first_active_lane()) d_leaf_wave++;
+               }
+               if (todo == 0u) {
+                  const int g = __float_as_int(q[0].y);
+                  const unsigned mask = __float_as_uint(q[0].z);
+                  if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group (gb == -1: none yet)
+                  gb = g;
+                  todo = mask & ~missed;
+                  if (STATS > 1) d_repeat += (unsigned) __popc(mask & missed);
+               } else {
+                  const unsigned bit0 = todo & (0u - todo), rest = todo & (todo - 1u), bit1 = rest & (0u - rest);
+                  const int gbase = gb & DESC_BASE_MASK;
+                  unsigned done = bit0 | bit1;
+                  if (CLOSEST) {
+                     if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += bit1 ? 2u : 1u;
+                     const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
+                     const bool m1 = bit1 != 0u && tri_meets(q[3], q[4], q[5], r, eps);
+                     missed |= (m0 ? 0u : bit0) | (m1 ? 0u : bit1);
+                     if (m0 || m1) {
+                        if (pend < 0) {
+                           pend = (gbase + __ffs((int) (m0 ? bit0 : bit1)) - 1) | (gb & DESC_IDENT);
+                           s_pkey[threadIdx.x] = ~lf;
+                           if (m0 && m1) done = bit0;   // the second one is met again next trip, when the first has been worked out
+                        } else {
+                           done &= ~((m0 ? bit0 : 0u) | (m1 ? bit1 : 0u));   // one waits already: it is worked out first
+                        }
+                     }
+                     want_resolve = done != (bit0 | bit1) || (FUSED && st.shadow && pend >= 0);
+                  } else {
+#pragma unroll
+                     for (int j = 0; j < LEAF_BATCH; j++) {
+                        const unsigned bit = j ? bit1 : bit0;
+                        if (bit != 0u) {
+                           if (STATS) n_tri++;
+                           float u, v, dist;
+                           V3 P;
+                           const bool met = tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist);
+                           if (!met) missed |= bit;
+                           const int gfx = (gbase + __ffs((int) bit) - 1) | (gb & DESC_IDENT);
+                           const int key = met ? __float_as_int(descs[(size_t) ~lf].x) : 0;
+                           if (met && (dist > a.sc.objs[st.k].shadow_distance) && beats(dist, key, gfx)) {
+                              ob_w = dist;
+                              ob_gf = gfx;
+                              ob_key = key;
+                              lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
+                              if (MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {   // device_util.h, shortcut 1
+                                 done = todo;          // nothing else in this leaf ...
+                                 gb &= ~DESC_MORE;     // ... or the rest of it ...
+                                 sp = bot;             // ... or anywhere else
+                                 cur = STACK_EMPTY;
+                                 break;
+                              }
+                           }
+                        }
+                     }
+                  }
+                  todo &= ~done;
+               }
+               if (todo == 0u) lf = (gb & DESC_MORE) ? lf - 1 : 0;   // this descriptor is finished: the leaf's next one, or the side is free
+            }
+         }
+         if (DEFER) resolve_req = __ballot(want_resolve) != 0ull;
+         continue;
       }
 
       // ---- one step per lane: an internal node (C) or one face of a leaf (D).  A trip that ran both
