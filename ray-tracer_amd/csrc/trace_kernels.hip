@@ -569,6 +569,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
    // faces of the leaf for such a lane; what the node side does ahead of a face that turns out to be hit is pruned when
    // the answer is in, exactly as a stolen subtree's is.
    int lf = 0;
+   int wg = 0;          // a leaf that waits in `cur` straight from its parent's record has its descriptor words with it:
+   unsigned wmask = 0;  // group word and face mask (wmask == 0: it came off the stack, its descriptor is to be read)
    int sp = 0, bot = 0;   // live stack entries are [bot, sp): thieves take from the bottom
    int age = 0;           // shadow modes: trips spent on the current ray (helpers inherit their victim's)
    int pend = -1;         // MODE_CLOSEST: a face of the current object that passed the triangle tests and whose point and
@@ -731,6 +733,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                if (STATS) (FUSED && st.shadow ? n_box_s : n_box)++;
                if (slab_test(r, nearp, farp, ob->bmin[0], ob->bmin[1], ob->bmin[2], ob->bmax[0], ob->bmax[1], ob->bmax[2], te)) {
                   cur = ob->root_entry;   // KDTree.getChildIntersection (bounds/KDTree.java:59-65)
+                  wmask = 0u;
                   todo = 0;
                }
             } else {
@@ -927,6 +930,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                age = v_age;
                cur = entry;
                lf = 0;
+               wmask = 0u;
                todo = 0;
                sp = bot = 0;
                ob_gf = -1;
@@ -958,9 +962,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
          // can be both).  Fetches are one after the other -- node records, then faces -- so that they share registers.
          if (STATS > 1 && st.role == ROLE_OWNER) d_ray_trips++;
          if (!CLOSEST) ++age;
-         if (lf == 0 && cur < 0) {   // the leaf side is free: the waiting leaf moves over (it came off the stack: its descriptor is read first)
+         if (lf == 0 && cur < 0) {   // the leaf side is free: the waiting leaf moves over
             lf = cur;
-            todo = 0u;
+            todo = 0u;   // (one that came off the stack: its descriptor is read first)
+            if (wmask != 0u) {
+               if (((wg ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
+               gb = wg;
+               todo = wmask & ~missed;
+               if (todo == 0u && !(wg & DESC_MORE)) lf = 0;   // meanwhile the ray has missed all of its faces next door
+               wmask = 0u;
+            }
             if (sp > bot) {
                --sp;
                cur = stack[sp * BLOCK_THREADS];
@@ -1038,17 +1049,21 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                // goes on with the other child or the stack.  A leaf child that finds the leaf side busy waits in `cur`.
                const bool lfree = lf == 0;
                int hand = 0;   // 1 / 2: the left / right child goes to the leaf side
+               int kept = 0;   // 1 / 2: the left / right child is what `cur` holds now
                if (lok && rok) {
                   const bool swap = tr < tl;   // nearest child first; the order never decides WHETHER a child is visited
                   const int n1 = swap ? re : le, n2 = swap ? le : re;
                   if (lfree && n1 < 0) {
                      hand = swap ? 2 : 1;
                      cur = n2;
+                     kept = swap ? 1 : 2;
                   } else if (lfree && n2 < 0) {
                      hand = swap ? 1 : 2;
                      cur = n1;
+                     kept = swap ? 2 : 1;
                   } else {
                      cur = n1;
+                     kept = swap ? 2 : 1;
                      stack[sp * BLOCK_THREADS] = n2;
                      ++sp;
                   }
@@ -1064,12 +1079,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                      }
                   } else {
                      cur = n1;
+                     kept = lok ? 1 : 2;
                   }
                } else if (sp > bot) {
                   --sp;
                   cur = stack[sp * BLOCK_THREADS];
                } else {
                   cur = STACK_EMPTY;
+               }
+               wmask = 0u;
+               if (kept != 0 && cur < 0) {
+                  wg = kept == 1 ? lg : rg;
+                  wmask = kept == 1 ? __float_as_uint(q4.y) : __float_as_uint(q4.w);
                }
                if (hand != 0) {
                   const int g = hand == 1 ? lg : rg;
