@@ -489,6 +489,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_DUAL_MIN
 #define WALK_DUAL_MIN 12
 #endif
+#ifndef WALK_DUAL_LEAF_MIN
+#define WALK_DUAL_LEAF_MIN WALK_DUAL_MIN
+#endif
 constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip
 static_assert(LEAF_BATCH == 2, "a leaf trip fetches two faces");
 
@@ -1106,7 +1109,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
          bool want_resolve = false;
          const bool in_leaf = lf < 0;
          const int n_leaf = __popcll(__ballot(in_leaf));
-         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= SIDE_MIN || !run_node);
+         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= WALK_DUAL_LEAF_MIN || !run_node);
          if (run_leaf) {
             const bool want_desc = in_leaf && todo == 0u;
             const unsigned rest0 = todo & (todo - 1u);
