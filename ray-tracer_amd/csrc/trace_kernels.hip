@@ -454,7 +454,10 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
 // lane roles
 enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_WAVES_PER_SIMD
-#define WALK_WAVES_PER_SIMD 5   // 96 VGPRs: the walker needs 86-90; held to 80 (6 waves) it spills 32 bytes per lane and loses more than the sixth wave gives
+#define WALK_WAVES_PER_SIMD 6   // closest-hit and fused walks, two-sided form: 80 VGPRs without scratch (3.61 ms at 5 waves, 3.51 at 6)
+#endif
+#ifndef WALK_SHADOW_WAVES_PER_SIMD
+#define WALK_SHADOW_WAVES_PER_SIMD 5   // the shadow forms carry more state (held to 80 VGPRs the exact form spills 32 bytes per lane)
 #endif
 #ifndef WALK_BIG_WAVES_PER_SIMD
 #define WALK_BIG_WAVES_PER_SIMD 5   // (6 waves at 80 VGPRs spill the burst's two passes in flight: Lucy-class 4K frame 54.1 ms at 5, 64.5 at 6)
@@ -464,9 +467,6 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #endif
 #ifndef WALK_REFILL_MIN
 #define WALK_REFILL_MIN 24
-#endif
-#ifndef WALK_BOTH_MIN
-#define WALK_BOTH_MIN 12
 #endif
 #ifndef WALK_RESOLVE_MIN
 #define WALK_RESOLVE_MIN 12
@@ -483,20 +483,19 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
 #endif
-#ifndef WALK_DUAL
-#define WALK_DUAL 0   // 1: a lane walks nodes and tests a leaf in the same trip (see "two sides" below)
-#endif
-#ifndef WALK_DUAL_MIN
-#define WALK_DUAL_MIN 12
-#endif
-#ifndef WALK_DUAL_LEAF_MIN
-#define WALK_DUAL_LEAF_MIN WALK_DUAL_MIN
+#ifndef WALK_SIDE_MIN
+#define WALK_SIDE_MIN 12   // (measured flat from 1 to 28 on the bench frame)
 #endif
 constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip
 static_assert(LEAF_BATCH == 2, "a leaf trip fetches two faces");
 
+constexpr int walk_waves_per_simd(int stats, int mode, int big)
+{
+   return big ? WALK_BIG_WAVES_PER_SIMD : (stats > 1 || mode == MODE_SHADOW || mode == MODE_SHADOW_ANY) ? WALK_SHADOW_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD;
+}
+
 template <int STATS, int MODE, int BIG>   // STATS: 0 none, 1 counts + timeline (light), 2 + walker diagnostics (heavy, changes occupancy); BIG: leaves of tens of faces (see "burst" below)
-__global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD, BIG ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD))) void walk_kernel(const WalkArgs a)
+__global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(walk_waves_per_simd(STATS, MODE, BIG), walk_waves_per_simd(STATS, MODE, BIG)))) void walk_kernel(const WalkArgs a)
 {
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
    __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
@@ -540,14 +539,14 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
    constexpr bool CLOSEST = MODE == MODE_CLOSEST || MODE == MODE_FUSED;   // rays come from the queue; faces wait in `pend`
    constexpr bool FUSED = MODE == MODE_FUSED;
    constexpr bool DEFER = CLOSEST || BIG != 0;   // faces that pass the triangle tests wait in `pend` for the resolve block
-   constexpr bool DUAL = BIG == 0 && WALK_DUAL != 0;
+   constexpr bool DUAL = BIG == 0;   // the two-sided trip ("two sides" below); the burst form keeps one cursor
    // Thresholds, measured on the bench frame and its shares: they were launch arguments while they were being
    // tuned; as constants they cost no scalar registers (the kernel is short of them: it spills scalars into vector lanes).
    constexpr int REFILL_MIN = CLOSEST ? WALK_REFILL_MIN : 64;   // refill once this many lanes are idle (or all of them); shadow waves refill whole
    constexpr int STEAL_MIN = CLOSEST ? 32 : 64;      // while the queue still has rays: steal once this many lanes are idle
    constexpr int TAIL_STEAL_MIN = 1;                 // once the queue is dry: steal with this many idle lanes
    constexpr int AGE_MIN = 8;                        // shadow modes: idle lanes help a ray that has been walked for this many trips at once
-   constexpr int BOTH_MIN = WALK_BOTH_MIN;           // a trip runs the node AND the leaf path only if each has this many lanes; else the majority's
+   constexpr int SIDE_MIN = WALK_SIDE_MIN;           // two-sided trip: a side with fewer lanes than this sits the trip out, unless the other does
    constexpr int RESOLVE_MIN = CLOSEST ? WALK_RESOLVE_MIN : 1;   // faces that passed the triangle tests wait until this many lanes hold one
    constexpr int BURST_MIN = WALK_BURST_MIN, BURST_NODE_FEW = WALK_BURST_NODE_FEW;   // BIG: see "burst"
    constexpr int ADMIN_MIN = WALK_ADMIN_MIN;         // lanes whose walk has ended wait until this many do before the bookkeeping block runs
@@ -982,7 +981,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
                cur = STACK_EMPTY;
             }
          }
-         constexpr int SIDE_MIN = WALK_DUAL_MIN;   // a side with fewer lanes than this sits the trip out, unless the other does
          const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
          const int n_node = __popcll(__ballot(in_node)), n_leaf0 = __popcll(__ballot(lf < 0));
          const bool run_node = n_node > 0 && (exhausted || n_node >= SIDE_MIN || n_node >= n_leaf0);
@@ -1109,7 +1107,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
          bool want_resolve = false;
          const bool in_leaf = lf < 0;
          const int n_leaf = __popcll(__ballot(in_leaf));
-         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= WALK_DUAL_LEAF_MIN || !run_node);
+         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= SIDE_MIN || !run_node);
          if (run_leaf) {
             const bool want_desc = in_leaf && todo == 0u;
             const unsigned rest0 = todo & (todo - 1u);
@@ -1190,38 +1188,25 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
          continue;
       }
 
-      // ---- one step per lane: an internal node (C) or one face of a leaf (D).  A trip that ran both
-      // paths for a handful of lanes each would spend most of its issue slots on masked-off lanes, so
-      // the minority state sits a trip out unless it is populous too (it becomes the majority soon).
+      // ---- the burst form (BIG): one cursor per lane -- an internal node (C) or a leaf whose chunks the wave tests (D').
+      // One fetch per lane per trip, issued up front: a node lane reads its 80-byte record, a leaf lane its 16-byte
+      // descriptor (a leaf that came off the stack; one entered from its parent has the words already); a leaf's faces
+      // are fetched by the lanes that test them, in the burst below.
       if (STATS > 1 && st.role == ROLE_OWNER) d_ray_trips++;
       if (!CLOSEST) ++age;
-      const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
-      const bool in_leaf = cur < 0;
-      const int n_node = __popcll(__ballot(in_node)), n_leaf = __popcll(__ballot(in_leaf));
-      // once the queue is dry what counts is how soon the last rays end, not issue slots: nobody sits out
-      const bool both = BIG || exhausted || (n_node >= BOTH_MIN && n_leaf >= BOTH_MIN);
-      const bool is_node = in_node && (both || n_node >= n_leaf);
-      const bool is_leaf = in_leaf && (both || n_leaf > n_node);
-      // One fetch per lane per trip, issued up front for every lane so that the latencies overlap: a node lane reads its
-      // 80-byte record; a leaf lane its 16-byte descriptor (a leaf that came off the stack; one entered from its parent
-      // has the words already) or the next two faces of the leaf it has not missed yet (48 bytes each, anywhere in its group's run of faces).  Lanes sitting the trip out read face 0.
-      // Testing two faces per trip halves the number of dependent round trips to memory, which is what a leaf costs.
-      constexpr int NQ = 6;
+      const bool is_node = (unsigned) cur < (unsigned) STACK_EMPTY;
+      const bool is_leaf = cur < 0;
+      const int n_node = __popcll(__ballot(is_node));
+      constexpr int NQ = 5;
       float4 q[NQ];
       {
          const bool want_desc = is_leaf && todo == 0u;
-         const unsigned rest = todo & (todo - 1u);
-         // (BIG: a leaf's faces are fetched by the lanes that test them, in the burst below)
-         const size_t f0 = !BIG && is_leaf && !want_desc ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) todo) - 1) : 0;
-         const size_t f1 = !BIG && is_leaf && rest != 0u ? (size_t) (gb & DESC_BASE_MASK) + (size_t) (__ffs((int) rest) - 1) : f0;
-         const float4 *pa = is_node ? nodes + NODE_F4 * (size_t) cur : (want_desc ? descs + (size_t) ~cur : gfaces + 3 * f0);
-         const float4 *pb = is_node ? pa + 3 : gfaces + 3 * f1;
+         const float4 *pa = is_node ? nodes + NODE_F4 * (size_t) cur : (want_desc ? descs + (size_t) ~cur : gfaces);
+         const float4 *pb = is_node ? pa + 3 : gfaces;
 #pragma unroll
          for (int j = 0; j < 3; j++) q[j] = pa[j];   // (a descriptor is one float4: the array is padded for the other two)
          q[3] = pb[0];
          q[4] = pb[1];   // a node record's fifth float4: its leaf children's descriptor words
-         q[5] = make_float4(0.f, 0.f, 0.f, 0.f);
-         if (!BIG && is_leaf) q[5] = pb[2];
       }
       const float4 na = q[0], nb = q[1], nc = q[2];
       const int4 nd = make_int4(__float_as_int(q[3].x), __float_as_int(q[3].y), __float_as_int(q[3].z), __float_as_int(q[3].w));
@@ -1324,7 +1309,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
       }
 
       bool want_resolve = false;
-      if (BIG) {
+      {
          // (D') leaves of tens of faces (the reference's depth limit of 20 on a mesh of millions: layout.h chunks of up to
          // 32 faces).  Two faces per lane and trip would leave a leaf lane sixteen trips in one chunk with the node lanes
          // masked off beside it.  Instead the WAVE tests chunks: each pass takes the next two leaf lanes, broadcasts their
@@ -1430,80 +1415,6 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(B
          if (is_leaf && todo == 0u) {   // this chunk is finished: the leaf's next one, or back to the stack
             if (gb & DESC_MORE) {
                cur -= 1;
-            } else if (sp > bot) {
-               --sp;
-               cur = stack[sp * BLOCK_THREADS];
-            } else {
-               cur = STACK_EMPTY;
-            }
-         }
-      } else if (is_leaf) {
-         // (D) a leaf (KDNode.java:110-118).  First trip: its descriptor -- which faces of its group it holds; the ones this
-         // ray has already missed (in a neighbouring leaf of the group) are not tested again.  Then two faces per trip,
-         // folded into object k's best by the order-independent rule (`beats`).
-         if (STATS > 1) {
-            d_leaf_lane++;
-            if (first_active_lane()) d_leaf_wave++;
-         }
-         if (todo == 0u) {
-            const int g = __float_as_int(q[0].y);
-            const unsigned mask = __float_as_uint(q[0].z);
-            if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group (gb == -1: none yet)
-            gb = g;
-            todo = mask & ~missed;
-            if (STATS > 1) d_repeat += (unsigned) __popc(mask & missed);
-         } else {
-            const unsigned bit0 = todo & (0u - todo), rest = todo & (todo - 1u), bit1 = rest & (0u - rest);
-            const int gbase = gb & DESC_BASE_MASK;
-            unsigned done = bit0 | bit1;
-            if (CLOSEST) {
-               if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += bit1 ? 2u : 1u;
-               const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
-               const bool m1 = bit1 != 0u && tri_meets(q[3], q[4], q[5], r, eps);
-               missed |= (m0 ? 0u : bit0) | (m1 ? 0u : bit1);
-               if (m0 || m1) {
-                  if (pend < 0) {
-                     pend = (gbase + __ffs((int) (m0 ? bit0 : bit1)) - 1) | (gb & DESC_IDENT);
-                     s_pkey[threadIdx.x] = ~cur;
-                     if (m0 && m1) done = bit0;   // the second one is met again next trip, when the first has been worked out
-                  } else {
-                     done &= ~((m0 ? bit0 : 0u) | (m1 ? bit1 : 0u));   // one waits already: it is worked out first
-                  }
-               }
-               // a face that could not be noted, or a shadow ray's first face (if it is accepted the walk is over): resolve at once
-               want_resolve = done != (bit0 | bit1) || (FUSED && st.shadow && pend >= 0);
-            } else {
-#pragma unroll
-               for (int j = 0; j < LEAF_BATCH; j++) {
-                  const unsigned bit = j ? bit1 : bit0;
-                  if (bit != 0u) {
-                     if (STATS) n_tri++;
-                     float u, v, dist;
-                     V3 P;
-                     const bool met = tri_test(q[3 * j], q[3 * j + 1], q[3 * j + 2], r, eps, u, v, P, dist);
-                     if (!met) missed |= bit;
-                     const int gfx = (gbase + __ffs((int) bit) - 1) | (gb & DESC_IDENT);
-                     const int key = met ? __float_as_int(descs[(size_t) ~cur].x) : 0;
-                     if (met && (dist > a.sc.objs[st.k].shadow_distance) && beats(dist, key, gfx)) {
-                        ob_w = dist;
-                        ob_gf = gfx;
-                        ob_key = key;
-                        lim2 = fminf(lim2, prune_limit2(r, dist, abs_max));
-                        if (MODE == MODE_SHADOW_ANY || (MODE == MODE_SHADOW && dist < safe_w)) {   // device_util.h, shortcut 1
-                           done = todo;          // nothing else in this leaf ...
-                           gb &= ~DESC_MORE;     // ... or the rest of it ...
-                           sp = bot;             // ... or anywhere else
-                           break;
-                        }
-                     }
-                  }
-               }
-            }
-            todo &= ~done;
-         }
-         if (todo == 0u) {   // this descriptor is finished: the leaf's next one, or back to the stack
-            if (gb & DESC_MORE) {
-               cur -= 1;   // ~(~cur + 1)
             } else if (sp > bot) {
                --sp;
                cur = stack[sp * BLOCK_THREADS];
