@@ -502,7 +502,7 @@ hipError_t upload_parts(mi355rt_scene *s, const std::vector<ScenePart> &parts, c
 // a pass renders at most this many sample slots at once (bounds the scratch: ~104 B per slot,
 // ~204 B with mirrors, 144 B more with a RefractionMaterial)
 constexpr size_t PASS_SLOTS = (size_t) 1 << 24;
-constexpr unsigned long long FUSE_MIN_SLOTS = 3000000ull;   // passes of at least this many samples walk shadow rays inside the primary launch
+constexpr unsigned long long FUSE_MIN_SLOTS = 1500000ull;   // passes of at least this many samples walk shadow rays inside the primary launch (measured on shares of the bench frame: 2.07 M samples 2.00 ms fused / 2.16 not; 1.04 M 1.50 / 1.45)
 
 int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_refraction)
 {
