@@ -199,6 +199,32 @@ __device__ __forceinline__ bool tri_meets(const float4 A, const float4 B, const 
    return true;
 }
 
+// tri_meets that also hands back the barycentrics it worked out, and the rest of tri_test from them: a face that passed
+// in the leaf step keeps (u, v) and the batched pass computes only the point and its distance (same expressions on the
+// same bits as tri_test, so the same answer).
+__device__ __forceinline__ bool tri_meets_uv(const float4 A, const float4 B, const float4 C, const Ray &r, float eps, float &u, float &v)
+{
+   const V3 p0 = mk3(A.x, A.y, A.z);
+   const V3 e1 = sub3(mk3(B.x, B.y, B.z), p0);
+   const V3 e2 = sub3(mk3(C.x, C.y, C.z), p0);
+   const V3 p = cross3(r.d, e2);
+   const float divisor = dot3(p, e1);
+   if ((divisor < eps) && (divisor > -eps)) return false;
+   const V3 T = sub3(r.o, p0);
+   const V3 q = cross3(T, e1);
+   u = dot3(p, T) / divisor;
+   if ((u < 0) || (u > 1)) return false;
+   v = dot3(q, r.d) / divisor;
+   if ((v < 0) || (v + u > 1)) return false;
+   return true;
+}
+__device__ __forceinline__ void tri_point(const float4 A, const float4 B, const float4 C, const Ray &r, float u, float v, V3 &P, float &dist)
+{
+   const float wb = 1.0f - u - v;
+   P = mk3(wb * A.x + u * B.x + v * C.x, wb * A.y + u * B.y + v * C.y, wb * A.z + u * B.z + v * C.z);
+   dist = distance3(r.o, P);
+}
+
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
 {
    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -500,6 +500,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
    __shared__ int s_stack[STACK_SLOTS * BLOCK_THREADS];
    __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
    __shared__ int s_pkey[BLOCK_THREADS];                              // per lane: the leaf descriptor its waiting face (`pend`) was met in
+   __shared__ float s_puv[2 * BLOCK_THREADS];                         // two-sided form: that face's barycentrics, as the leaf step worked them out
    const int lane = threadIdx.x & 63;
    const int wave_base = threadIdx.x & ~63;
    int *__restrict__ stack = s_stack + threadIdx.x;
@@ -636,7 +637,8 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                const float4 A = t[0], B = t[1], C = t[2];
                float u, v, dist;
                V3 P;
-               (void) tri_test(A, B, C, r, eps, u, v, P, dist);
+               if (DUAL) tri_point(A, B, C, r, s_puv[threadIdx.x], s_puv[BLOCK_THREADS + threadIdx.x], P, dist);
+               else (void) tri_test(A, B, C, r, eps, u, v, P, dist);
                const int key = __float_as_int(descs[(size_t) s_pkey[threadIdx.x]].x);
                if ((dist > sd) && beats(dist, key, pend)) {
                   ob_w = dist;
@@ -1138,13 +1140,16 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                   unsigned done = bit0 | bit1;
                   if (CLOSEST) {
                      if (STATS) (FUSED && st.shadow ? n_tri_s : n_tri) += bit1 ? 2u : 1u;
-                     const bool m0 = tri_meets(q[0], q[1], q[2], r, eps);
-                     const bool m1 = bit1 != 0u && tri_meets(q[3], q[4], q[5], r, eps);
+                     float u0 = 0.0f, v0 = 0.0f, u1 = 0.0f, v1 = 0.0f;
+                     const bool m0 = tri_meets_uv(q[0], q[1], q[2], r, eps, u0, v0);
+                     const bool m1 = bit1 != 0u && tri_meets_uv(q[3], q[4], q[5], r, eps, u1, v1);
                      missed |= (m0 ? 0u : bit0) | (m1 ? 0u : bit1);
                      if (m0 || m1) {
                         if (pend < 0) {
                            pend = (gbase + __ffs((int) (m0 ? bit0 : bit1)) - 1) | (gb & DESC_IDENT);
                            s_pkey[threadIdx.x] = ~lf;
+                           s_puv[threadIdx.x] = m0 ? u0 : u1;   // the batched pass goes on from here
+                           s_puv[BLOCK_THREADS + threadIdx.x] = m0 ? v0 : v1;
                            if (m0 && m1) done = bit0;   // the second one is met again next trip, when the first has been worked out
                         } else {
                            done &= ~((m0 ? bit0 : 0u) | (m1 ? bit1 : 0u));   // one waits already: it is worked out first
