@@ -1,5 +1,6 @@
 """The walker's other forms against its default form, frame for frame (bit-identical ids, objects, w and radiance):
-the burst form for leaves of tens of faces (trace_kernels.hip, MI355RT_BIG_LEAVES), the work-list walker
+the burst form for leaves of tens of faces and the two-sided form for small leaves, each forced on the other's scenes
+(trace_kernels.hip, MI355RT_BIG_LEAVES=1/0), the work-list walker
 (walk_lds.hip, MI355RT_WALKER=lds), and launches trimmed more or less than the default.  The oracle pins the default form elsewhere."""
 import pytest
 
@@ -31,6 +32,7 @@ def _scenes(rt):
 
 @pytest.mark.parametrize("env", [{"MI355RT_BIG_LEAVES": "1"}, {"MI355RT_WALKER": "lds"}, {"MI355RT_WALKER": "lds", "MI355RT_FUSE_SHADOW": "0"},
                                  {"MI355RT_BIG_LEAVES": "1", "MI355RT_FUSE_SHADOW": "1"},
+                                 {"MI355RT_BIG_LEAVES": "0"}, {"MI355RT_BIG_LEAVES": "0", "MI355RT_FUSE_SHADOW": "1"},   # the two-sided form on leaves of many chunks too
                                  {"MI355RT_TRIM": "0"}, {"MI355RT_TRIM_PRIMARY_X2": "400", "MI355RT_TRIM_SHADOW_X2": "400"}])   # launches not trimmed / trimmed to the minimum
 def test_other_walker_forms_render_the_same_frames(rt, monkeypatch, env):
     import torch
