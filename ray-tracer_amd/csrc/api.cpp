@@ -171,6 +171,7 @@ struct mi355rt_scene {
    float abs_max = 0.f;
    float max_normal_len = 0.f;
    bool has_mirror = false;
+   bool plain_materials = true;   // ColorInformation only
    uint64_t device_bytes = 0;
    uint32_t *d_counters = nullptr;   // CNT_WORDS
    unsigned long long *h_readback = nullptr;   // page-locked, N_STATS words: where run_frame reads queue sizes and counters back to
@@ -719,6 +720,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       // afresh over all waves end sooner than each wave's own).
       p.fused_shadow = fuse_policy == 2 || (fuse_policy == 1 && slots >= FUSE_MIN_SLOTS) ? 1 : 0;
       p.phong_in_shade = p.fused_shadow && !s->has_mirror && !s->has_refraction ? 1 : 0;
+      p.plain_materials = s->plain_materials ? 1 : 0;
       HIP_TRY(hipMemsetAsync(p.counters, 0, CNT_WORDS * sizeof(uint32_t), stream));
       HIP_TRY(timer.run(MI355RT_K_GENERATE, [&] { return launch_generate(p, stream); }));
       int cursor_set = 0;   // each persistent launch owns 8 cursor words (zeroed with the rest at pass start)
@@ -865,6 +867,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             std::memcpy(ext.cell, od.ext.checker_cell, sizeof(ext.cell));
             if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
             if (md.material.kind == MI355RT_MAT_REFRACTION) s->has_refraction = true;
+            if (md.material.kind != MI355RT_MAT_COLOR) s->plain_materials = false;
             if (od.kind != MI355RT_OBJ_MESH) {
                const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
                if (!err.empty()) {

@@ -183,6 +183,7 @@ struct FrameArgs {
    int32_t shadow_any_hit;   // host-proven: any accepted hit occludes (see api.cpp)
    int32_t fused_shadow;     // the primary launch walked the shadow rays too (walk_kernel MODE_FUSED): mat0[].w is already set
    int32_t phong_in_shade;   // fused_shadow and no bounce rays in the scene: shade_kernel<0> has all PhongLightingModel needs
+   int32_t plain_materials;  // every object's material is a ColorInformation: the shade launch takes the kernel without the other materials' code
    const float *brdf_dirs;      // n_dirs * 3, remapped
    const float *brdf_weights;   // n_materials * n_dirs
    int32_t n_dirs, n_materials;

@@ -1491,8 +1491,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
 
 // ---------------------------------------------------------------- shade hits
 // LEVEL 0: primary queue (Q0).  LEVEL 1: a secondary (mirror bounce) queue; aux >> 16 = bounces so
-// far, slot = index of the path's primary queue entry.
-template <int LEVEL>
+// far, slot = index of the path's primary queue entry.  PLAIN: every material of the scene is a ColorInformation (the
+// table search, bounce rays and the checkerboard are compiled out: 161 -> far fewer registers, no list in LDS).
+template <int LEVEL, int PLAIN>
 __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p, const float *rays, const float *hits,
                                                               const int32_t *hit_obj, int count_index, float *rays_next,
                                                               int next_count_index)
@@ -1552,7 +1553,12 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
             n_terms++;
          }
          const bool cut = ob.kind != OBJ_MESH && bounces >= p.max_recursion_depth;   // SceneObject.java:65-67; KDTree.java:77-80 has none
-         if (!cut && m.kind == MAT_REFLECTION && bounces < p.max_mirror_bounces) {
+         if (PLAIN) {
+            mat[0] = m.diffuse[0];   // ColorInformation.java:35-37
+            mat[1] = m.diffuse[1];
+            mat[2] = m.diffuse[2];
+            have_mat = true;
+         } else if (!cut && m.kind == MAT_REFLECTION && bounces < p.max_mirror_bounces) {
             // ReflectionMaterial.java:16-17 + Camera.java:196-200 (offset origin, Ray ctor normalises again)
             sec_o = add3(P, scale3(N, p.sc.epsilon));
             sec_d = normalize3(reflect3(N, D));
@@ -1643,7 +1649,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p,
    // a path's shadow ray and bounce ray stay in the path's band
    const unsigned si = (unsigned) band * p.band_cap + block_queue_push<BLOCK_THREADS / 64>(p.counters + CNT_SHADOW + band, push_shadow, s_cnt);
    if (push_shadow) p.shadow[si] = path;
-   if (rays_next) {
+   if (!PLAIN && rays_next) {
       const unsigned qi = (unsigned) band * p.band_cap + block_queue_push<BLOCK_THREADS / 64>(p.counters + next_count_index + band, push_sec, s_cnt);
       if (push_sec) store_ray(rays_next, qi, sec_o, sec_d, path, sec_aux);
    }
@@ -1995,11 +2001,14 @@ hipError_t launch_shade(const FrameArgs &p, int level, const float *rays, const 
 {
    if (!max_items) return hipSuccess;
    const unsigned grid = bounded_grid(n_cus, max_items);
-   if (level == 0)
-      hipLaunchKernelGGL(shade_kernel<0>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
+   if (level == 0 && p.plain_materials)
+      hipLaunchKernelGGL((shade_kernel<0, 1>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
+                         next_count_index);
+   else if (level == 0)
+      hipLaunchKernelGGL((shade_kernel<0, 0>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
                          next_count_index);
    else
-      hipLaunchKernelGGL(shade_kernel<1>, dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
+      hipLaunchKernelGGL((shade_kernel<1, 0>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, p, rays, hits, hit_obj, count_index, rays_next,
                          next_count_index);
    return hipGetLastError();
 }

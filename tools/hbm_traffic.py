@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {"walk_kernel<0, 0": "walk_primary", "walk_kernel<0, 3": "walk_primary", "walk_kernel<0, 2": "walk_shadow", "walk_kernel<0, 1": "walk_shadow",
-         "generate_kernel": "generate", "shade_kernel<0>": "shade", "shade_kernel<1>": "shade", "phong_kernel": "phong", "resolve_kernel": "resolve"}
+         "generate_kernel": "generate", "shade_kernel<0,": "shade", "shade_kernel<1,": "shade", "phong_kernel": "phong", "resolve_kernel": "resolve"}
 
 
 def per_kernel(d):
