@@ -1493,8 +1493,11 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
 // LEVEL 0: primary queue (Q0).  LEVEL 1: a secondary (mirror bounce) queue; aux >> 16 = bounces so
 // far, slot = index of the path's primary queue entry.  PLAIN: every material of the scene is a ColorInformation (the
 // table search, bounce rays and the checkerboard are compiled out: 161 -> far fewer registers, no list in LDS).
+#ifndef SHADE_WAVES
+#define SHADE_WAVES 4   // 128 VGPRs (20 bytes of scratch): the table search is latency-bound, Buddha-class shade 0.74 -> 0.69 ms
+#endif
 template <int LEVEL, int PLAIN>
-__global__ __launch_bounds__(BLOCK_THREADS) void shade_kernel(const FrameArgs p, const float *rays, const float *hits,
+__global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(PLAIN ? 5 : SHADE_WAVES, PLAIN ? 5 : SHADE_WAVES))) void shade_kernel(const FrameArgs p, const float *rays, const float *hits,
                                                               const int32_t *hit_obj, int count_index, float *rays_next,
                                                               int next_count_index)
 {
