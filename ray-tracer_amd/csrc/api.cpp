@@ -502,7 +502,33 @@ hipError_t upload_parts(mi355rt_scene *s, const std::vector<ScenePart> &parts, c
 
 // a pass renders at most this many sample slots at once (bounds the scratch: ~104 B per slot,
 // ~204 B with mirrors, 144 B more with a RefractionMaterial)
-constexpr size_t PASS_SLOTS = (size_t) 1 << 24;
+// Every pass ends on its longest rays with the chip draining, so passes are as large as memory allows: 2^27 slots (a 4K frame
+// at 16 spp in one pass: 14 GB of scratch for a mesh scene, 27 GB with a mirror) unless that is more than a quarter of the
+// HBM that is free when the scratch has to grow; measured 4K x 16 spp, 2^24 against 2^27: Thai-class 15.2 -> 11.9 ms,
+// Lucy-class 51.5 -> 48.3.  MI355RT_PASS_SLOTS_LOG2 forces a size (the tests use it to run many small passes).
+constexpr size_t PASS_SLOTS_DEFAULT_LOG2 = 27, PASS_SLOTS_MIN_LOG2 = 22, PASS_SLOTS_MAX_LOG2 = 28;
+size_t scratch_bytes_per_slot(bool with_mirror, bool with_refraction)
+{
+   return 104 + 1 + (with_mirror ? 100 : 0) + (with_refraction ? 16 * (1 + MAX_REFRACTION_TERMS) : 0);
+}
+size_t pass_slots(const mi355rt_scene *s, size_t frame_slots, bool with_mirror, bool with_refraction)
+{
+   const char *v = getenv("MI355RT_PASS_SLOTS_LOG2");   // read per frame
+   if (v && *v) {
+      const long l = atol(v);
+      return (size_t) 1 << (l < 12 ? 12 : (l > (long) PASS_SLOTS_MAX_LOG2 ? (long) PASS_SLOTS_MAX_LOG2 : l));
+   }
+   size_t slots = (size_t) 1 << PASS_SLOTS_DEFAULT_LOG2;
+   const FrameScratch &fs = s->scratch;
+   const bool fits = (fs.with_mirror || !with_mirror) && (fs.with_refraction || !with_refraction);
+   if (fits && fs.cap >= std::min(frame_slots, slots)) return slots;   // nothing to allocate
+   size_t free_b = 0, total_b = 0;
+   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return (size_t) 1 << PASS_SLOTS_MIN_LOG2;
+   free_b += fs.bytes;   // what the scratch holds now is given back first
+   while (slots > ((size_t) 1 << PASS_SLOTS_MIN_LOG2) && slots / 2 >= frame_slots) slots >>= 1;   // (no larger than the frame needs)
+   while (slots > ((size_t) 1 << PASS_SLOTS_MIN_LOG2) && slots * scratch_bytes_per_slot(with_mirror, with_refraction) > free_b / 4) slots >>= 1;
+   return slots;
+}
 constexpr unsigned long long FUSE_MIN_SLOTS = 1500000ull;   // passes of at least this many samples walk shadow rays inside the primary launch (measured on shares of the bench frame: 2.07 M samples 2.00 ms fused / 2.16 not; 1.04 M 1.50 / 1.45)
 
 int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_refraction)
@@ -591,7 +617,7 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    if (int rc = check_settings(st)) return rc;
    if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
    if ((uint64_t) cam->width * (uint64_t) cam->height > (uint64_t) 1 << 30) return fail(MI355RT_E_LIMIT, "image larger than 2^30 pixels");
-   if ((size_t) st->multi_samples * 64 > PASS_SLOTS) return fail(MI355RT_E_LIMIT, "multi_samples too large");
+   if ((size_t) st->multi_samples * 64 > ((size_t) 1 << 24)) return fail(MI355RT_E_LIMIT, "multi_samples too large");
    std::memset(&p, 0, sizeof(p));
    p.sc.objs = s->d_objs;
    p.sc.nodes = s->d_nodes;
@@ -680,12 +706,14 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       if (int rc = resolve_times(s)) return rc;
    LaunchTimer timer(s, collect_times, stream);
    const size_t slots_per_micro = (size_t) 64 * (size_t) p.multi_samples;
-   const long long micro_per_pass = fixed ? n_micro : (long long) std::max<size_t>(1, PASS_SLOTS / slots_per_micro);
+   const bool with_mirror = s->has_mirror || s->has_refraction;
+   const long long micro_per_pass =
+      fixed ? n_micro : (long long) std::max<size_t>(1, pass_slots(s, (size_t) n_micro * slots_per_micro, with_mirror, s->has_refraction) / slots_per_micro);
    const long long first_pass = std::min(n_micro, micro_per_pass);
    const size_t first_slots = (size_t) ((first_pass + N_BANDS - 1) / N_BANDS) * N_BANDS * slots_per_micro;
    if (fixed) {
       if (fixed->cap < first_slots) return fail(MI355RT_E_LIMIT, "frame does not fit the fixed scratch");
-   } else if (int rc = ensure_scratch(s, first_slots, s->has_mirror || s->has_refraction, s->has_refraction)) {
+   } else if (int rc = ensure_scratch(s, first_slots, with_mirror, s->has_refraction)) {
       return rc;
    }
    const FrameScratch &fs = fixed ? *fixed : s->scratch;

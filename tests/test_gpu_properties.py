@@ -115,9 +115,11 @@ def test_compact_blocks_unpack_to_the_whole_frame(rt):
     scene.close()
 
 
-def test_multi_pass_frame(rt, orc):
-    """A frame of more than 2^24 sample slots runs as several passes of the pipeline (api.cpp PASS_SLOTS)."""
+def test_multi_pass_frame(rt, orc, monkeypatch):
+    """A frame of more sample slots than a pass holds runs as several passes of the pipeline (api.cpp pass_slots; the
+    default pass, 2^27 slots, is forced down to 2^24 here)."""
     from helpers import compare_frames
+    monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", "24")
     scene, (v, i), cfg, light = _scene(rt, 5000, name="bunny")
     W, H, ms = 1920, 1088, 9       # 18.8 M samples -> 2 passes
     cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=3)
@@ -130,6 +132,34 @@ def test_multi_pass_frame(rt, orc):
     ids_equal, w_equal, max_rel, n_diff = compare_frames(cam._rgb_rows, cam.hit_id.T, cam.hit_w.T, o, g_obj=cam.hit_obj.T)
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     osc.close()
+    scene.close()
+
+
+def test_frames_do_not_depend_on_the_pass_size(rt, monkeypatch):
+    """How a frame is cut into passes is a matter of memory and speed only: a mirror over a floor rendered in passes of
+    2^14, 2^17 and the default number of slots gives the same bits."""
+    import torch
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+    v, i = rt.meshgen.blob(60000, span=2.0, seed=12)
+    fv, fi = rt.meshgen.quad(-1.2, 3.0)
+    objs = [rt.TriangleMesh((v, i), rt.ReflectionMaterial((0.9, 0.9, 1.0)), True), rt.TriangleMesh((fv, fi), rt.ColorInformation((0.8, 0.3, 0.2)), True)]
+    scene = rt.Scene(objs, light, (0, -25, 0), rt.PhongLightingModel(light, objs), 40.0)
+    W, H, ms = 640, 400, 3
+    cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=8)
+    frames = []
+    for log2 in ("14", "17", None):
+        if log2 is None:
+            monkeypatch.delenv("MI355RT_PASS_SLOTS_LOG2", raising=False)
+        else:
+            monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", log2)
+        f, rgb, ids, w = _device_frame(rt, cam)
+        cam.render_device(f)
+        torch.cuda.synchronize()
+        frames.append((rgb.clone(), ids.clone(), w.clone()))
+    assert int((frames[0][1] >= 0).sum()) > W * H // 20
+    for other in frames[1:]:
+        for a, b in zip(frames[0], other):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     scene.close()
 
 
@@ -356,11 +386,12 @@ def test_buddha_config_brdf_full_size(rt, orc):
     scene.close()
 
 
-def test_thai_class_mirror_4k_two_passes(rt, orc):
+def test_thai_class_mirror_4k_two_passes(rt, orc, monkeypatch):
     """The shape of BASELINE configs[3]/[4] at a size the oracle can follow: a 2-million-face mesh of span 400
     (EPSILON = 1e-3, Scene.java:36) with ReflectionMaterial over a floor, 3840x2160, 3 spp = 24.9 M samples in two
     passes with mirror bounces; the oracle checks every 211th pixel."""
     from helpers import Pair
+    monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", "24")
     v, i = rt.meshgen.blob(2000000, span=400.0, stretch=(0.59, 1.0, 0.52), seed=4)
     fv, fi = rt.meshgen.quad(-205.0, 230.0)
     pair = Pair([(v, i, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))), (fv, fi, None, rt.ColorInformation((0.8, 0.3, 0.2)))],
@@ -400,7 +431,7 @@ def test_lucy_class_parity_4k(rt, orc):
 
 
 def test_lucy_config_full_size_properties(rt):
-    """BASELINE configs[4] at full size -- 28,055,742 faces, 3840x2160, 16 spp (8 passes), Phong, exact shadows -- through
+    """BASELINE configs[4] at full size -- 28,055,742 faces, 3840x2160, 16 spp (one pass of 2^27 slots), Phong, exact shadows -- through
     properties that need no oracle: every sample is a primary ray, every hit sample casts one shadow ray, two renders are
     bit-identical (whatever wave walked or stole what), and the first sample's hits agree with a 1-spp frame's."""
     import torch
@@ -434,7 +465,7 @@ def test_lucy_config_full_size_properties(rt):
 def test_thai_config_full_size_16spp(rt, orc):
     """BASELINE configs[3] at full size: the Thai-statuette stand-in, 10,000,000 faces of span 400 (EPSILON = 1e-3) with
     ReflectionMaterial over a floor (a lone mirrored mesh reflects nothing: ReflectionMaterial.java:14-24 skips the object
-    itself), orientation (0,0,0) tilted to show the floor, 3840x2160 at 16 spp = 132.7 M samples in 8 passes with mirror
+    itself), orientation (0,0,0) tilted to show the floor, 3840x2160 at 16 spp = 132.7 M samples in one pass with mirror
     bounces.  The oracle checks every 499th pixel (all 16 samples, shadow and bounce rays of each)."""
     from helpers import Pair
     cfg = rt.meshgen.STANFORD["thai"]
