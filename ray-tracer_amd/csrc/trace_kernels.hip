@@ -462,6 +462,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_BIG_WAVES_PER_SIMD
 #define WALK_BIG_WAVES_PER_SIMD 5   // (6 waves at 80 VGPRs spill the burst's two passes in flight: Lucy-class 4K frame 54.1 ms at 5, 64.5 at 6)
 #endif
+#ifndef WALK_SHADOW_BLOCK
+#define WALK_SHADOW_BLOCK (1 << 13)   // power of two, a multiple of WALK_SHADOW_SPREAD (4K x 16 spp in one pass, shadow walk: Lucy-class 25.0 ms unblocked, 21.5 at 2^17, 20.3 at 2^13, 19.7 at 2^9; Thai-class 6.5 / 6.1 / 5.7 / 6.2; Dragon-class 0.92 / 0.92 / 0.92 / 1.33)
+#endif
 #ifndef WALK_SHADOW_SPREAD
 #define WALK_SHADOW_SPREAD 64   // power of two
 #endif
@@ -839,10 +842,17 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                if (STATS) t_exhausted = wall_clock64();
             } else if (st.role == ROLE_IDLE) {
                const unsigned logical = base + (unsigned) rank_below(idle);
-               const unsigned rel = (logical % SPREAD) * rows + logical / SPREAD;
-               const unsigned my = lo + rel;
-               const unsigned limit = logical < rows * SPREAD ? lo + count : 0u;
-               if (my < limit) {
+               // (the matrix is per block of WALK_SHADOW_BLOCK rays, so that what the chip works on at one time stays a patch
+               // of the image however long the queue is: with a 4K x 16 spp frame as ONE pass and the whole band as one matrix
+               // the Lucy-class shadow launch read 185 GB, L2 hit 0.39, against 8 x 13 GB as eight passes)
+               constexpr unsigned BLK = CLOSEST ? 1u : (unsigned) WALK_SHADOW_BLOCK;
+               const unsigned blk0 = CLOSEST ? logical : logical & ~(BLK - 1u), off = CLOSEST ? 0u : logical & (BLK - 1u);
+               const unsigned bsize = blk0 < count ? min(BLK, count - blk0) : 0u;
+               const unsigned rows_b = (bsize + SPREAD - 1u) / SPREAD;
+               const unsigned idx = (off % SPREAD) * rows_b + off / SPREAD;
+               const unsigned my = lo + blk0 + idx;
+               const bool mine = logical < rows * SPREAD && idx < bsize;
+               if (mine) {
                   qi = my;
                   V3 o, d;
                   if (CLOSEST) {
