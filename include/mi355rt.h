@@ -241,7 +241,11 @@ int mi355rt_host_free(void *ptr);
  * launch follows); settings.collect_stats has MI355RT_COLLECT_COUNTS / _DIAG (one read-back of the counters per
  * pass); and a call that needs more frame scratch than the scene holds so far (the first one, or a larger frame)
  * frees and allocates device memory, which synchronises the device.  Mesh-only Phong / plain frames of a size the
- * scene has rendered before return at once: that is what frames in flight on several streams rely on. */
+ * scene has rendered before return at once: that is what frames in flight on several streams rely on.
+ * Frame scratch: about 104 bytes per sample slot of a pass (204 with a mirror, 348 with refraction), a pass being the
+ * whole frame up to 2^27 slots -- a 3840x2160 frame at 16 spp is one pass and 14 GB -- or less when that would take
+ * over a quarter of the device memory that is free when the scratch has to grow (MI355RT_PASS_SLOTS_LOG2 forces a
+ * size); a frame of more slots runs as several passes.  How a frame is cut into passes never changes its pixels. */
 int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings,
                           const mi355rt_frame *frame, void *hip_stream);
 
