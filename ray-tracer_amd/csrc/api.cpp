@@ -529,7 +529,7 @@ size_t pass_slots(const mi355rt_scene *s, size_t frame_slots, bool with_mirror, 
    while (slots > ((size_t) 1 << PASS_SLOTS_MIN_LOG2) && slots * scratch_bytes_per_slot(with_mirror, with_refraction) > free_b / 4) slots >>= 1;
    return slots;
 }
-constexpr unsigned long long FUSE_MIN_SLOTS = 1500000ull;   // passes of at least this many samples walk shadow rays inside the primary launch (measured on shares of the bench frame: 2.07 M samples 2.00 ms fused / 2.16 not; 1.04 M 1.50 / 1.45)
+constexpr unsigned long long FUSE_MIN_SLOTS = 100000ull;   // passes of at least this many samples walk shadow rays inside the primary launch (with short passes dealt out spread the fused launch wins on every share of the bench frame measured: 8.3 / 2.1 / 1.0 / 0.26 M samples 3.69 / 1.86 / 1.18 / 0.58 ms against 4.06 / 2.06 / 1.37 / 0.72)
 
 int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_refraction)
 {
@@ -743,9 +743,8 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       p.micro_end = (int32_t) m1;
       p.band_cap = (uint32_t) ((((unsigned long long) (m1 - m0) + N_BANDS - 1) / N_BANDS) * slots_per_micro);
       const unsigned long long slots = (unsigned long long) p.band_cap * N_BANDS;   // queue capacity of the pass
-      // Measured on the bench frame and on 1/2, 1/4, 1/8 of it: the fused launch wins on 4 M samples and more (no second
-      // launch draining the chip), ties at 2 M and loses below (a short launch is mostly tail, and shadow rays dealt out
-      // afresh over all waves end sooner than each wave's own).
+      // (round 1's walker lost with the fused launch below 3 M samples: a short launch is mostly its end, and shadow rays
+      // dealt out afresh over all waves ended sooner than each wave's own; dealt out spread, short fused launches win too)
       p.fused_shadow = fuse_policy == 2 || (fuse_policy == 1 && slots >= FUSE_MIN_SLOTS) ? 1 : 0;
       p.phong_in_shade = p.fused_shadow && !s->has_mirror && !s->has_refraction ? 1 : 0;
       p.plain_materials = s->plain_materials ? 1 : 0;

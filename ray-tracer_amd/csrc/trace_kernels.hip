@@ -845,13 +845,27 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                // (the matrix is per block of WALK_SHADOW_BLOCK rays, so that what the chip works on at one time stays a patch
                // of the image however long the queue is: with a 4K x 16 spp frame as ONE pass and the whole band as one matrix
                // the Lucy-class shadow launch read 185 GB, L2 hit 0.39, against 8 x 13 GB as eight passes)
-               constexpr unsigned BLK = CLOSEST ? 1u : (unsigned) WALK_SHADOW_BLOCK;
-               const unsigned blk0 = CLOSEST ? logical : logical & ~(BLK - 1u), off = CLOSEST ? 0u : logical & (BLK - 1u);
-               const unsigned bsize = blk0 < count ? min(BLK, count - blk0) : 0u;
-               const unsigned rows_b = (bsize + SPREAD - 1u) / SPREAD;
-               const unsigned idx = (off % SPREAD) * rows_b + off / SPREAD;
-               const unsigned my = lo + blk0 + idx;
-               const bool mine = logical < rows * SPREAD && idx < bsize;
+               unsigned my;
+               bool mine;
+               if (CLOSEST) {
+                  // (SPREAD is 1 here: the cursor counts rays.  The dealing, if any, is a launch argument -- walk_args.h: per
+                  // block the largest whole matrix of 2^sl columns is read down its columns, the block's last few rays in order)
+                  const unsigned sl = a.primary_spread & 0xffu, bl = (a.primary_spread >> 8) & 0xffu;
+                  const unsigned blk0 = (logical >> bl) << bl, off = logical - blk0;
+                  const unsigned bsize = blk0 < count ? min(1u << bl, count - blk0) : 0u;
+                  const unsigned rows_f = bsize >> sl, full = rows_f << sl;
+                  const unsigned dealt = (off & ((1u << sl) - 1u)) * rows_f + (off >> sl);
+                  my = lo + blk0 + (a.primary_spread != 0u && off < full ? dealt : off);
+                  mine = logical < count;
+               } else {
+                  constexpr unsigned BLK = (unsigned) WALK_SHADOW_BLOCK;
+                  const unsigned blk0 = logical & ~(BLK - 1u), off = logical & (BLK - 1u);
+                  const unsigned bsize = blk0 < count ? min(BLK, count - blk0) : 0u;
+                  const unsigned rows_b = (bsize + SPREAD - 1u) / SPREAD;
+                  const unsigned idx = (off % SPREAD) * rows_b + off / SPREAD;
+                  my = lo + blk0 + idx;
+                  mine = logical < rows * SPREAD && idx < bsize;
+               }
                if (mine) {
                   qi = my;
                   V3 o, d;
@@ -1993,6 +2007,16 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.trim_unit = tunable("MI355RT_BLOCKS_PER_CU", 0) > 0 || !tunable("MI355RT_TRIM", 1) ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) tunable("MI355RT_TRIM_PRIMARY_X2", 5) / 2u;   // 2.5 rays per lane
    a.trim_step = (unsigned) n_cus;
    a.trim_lo = 2u;
+   {   // Short passes are dealt out spread (walk_args.h).  Measured on shares of the bench frame, one frame at a time / two in
+       // flight: 1.0 M samples 1.52 / 0.86 ms in order, 1.35 / 0.80 with 64 columns per 16,384 rays; 2.1 M samples 2.00 / 1.25 in
+       // order, 1.75 / 1.43 with 16 per 4,096, 1.86 / 1.29 with 8 per 1,024 (balance costs coherence: what one frame gains two
+       // in flight pay); 4.1 M 2.53 / 1.81 against 2.44 / 2.07; the whole 8.3 M-sample frame 3.69 / 2.99 against 3.78 / 3.38.
+      const int sl = tunable("MI355RT_SPREAD_SL", -1), bl = tunable("MI355RT_SPREAD_BL", -1);
+      const unsigned long long spread_max = (unsigned long long) tunable("MI355RT_SPREAD_PRIMARY_MAX", 3000000);
+      a.primary_spread = 0u;
+      if (max_items < spread_max) a.primary_spread = max_items < 1500000ull ? (6u | (14u << 8)) : (3u | (10u << 8));
+      if (a.primary_spread != 0u && sl >= 0 && bl >= sl && bl < 32) a.primary_spread = (unsigned) sl | ((unsigned) bl << 8);
+   }
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, big_leaves(sc) ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD));
    if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
    return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
@@ -2056,6 +2080,7 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.trim_unit = tunable("MI355RT_BLOCKS_PER_CU_SHADOW", 0) > 0 || !tunable("MI355RT_TRIM", 1) ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) tunable("MI355RT_TRIM_SHADOW_X2", big_leaves(p.sc) ? 3 : 12) / 2u;   // 6 rays per lane; 1.5 where a ray is hundreds of triangle tests (measured: Thai- and Lucy-class)
    a.trim_step = (unsigned) n_cus;
    a.trim_lo = 1u;
+   a.primary_spread = 0u;
    const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, big_leaves(p.sc) ? WALK_BIG_WAVES_PER_SIMD : 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
    if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream, n_cus, max_items);

@@ -28,6 +28,11 @@ struct WalkArgs {
    // The host sizes the grid from the pass's samples (the queue's length is only known on the device); a workgroup
    // beyond round(rays queued / trim_unit) x trim_step, at least trim_lo, leaves at once (0: no trimming).
    uint32_t trim_unit, trim_step, trim_lo;
+   // closest-hit queues: 0 = rays are taken in queue order (image order: coherent waves, what long passes want); else the
+   // queue is dealt out as the shadow queue is -- transposed, spread_log2 columns per block of 2^block_log2 rays -- so
+   // that the long rays of one patch of the image land in different waves (short passes are all launch end: the slowest
+   // wave of a 1/8 share of the bench frame took 1.0 ms, the average one 0.3).  low byte spread_log2, next byte block_log2.
+   uint32_t primary_spread;
 };
 
 // walk_lds.hip: the same walks by the work-list kernel; mode = one of MODE_*, stats 0 / 1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # shares of the bench frame: one frame at a time and two in flight, fused / unfused
 mkdir -p gpurun_out/shares
-for n in 2 4 8; do
+for n in ${SHARES:-2 4 8}; do
   for f in d 0 1; do
     envs=""; [ $f != d ] && envs="MI355RT_FUSE_SHADOW=$f"
     env $envs timeout -k 10 120 python bench.py --no-cpu-baseline --no-extras --emulate-world $n --steps 20 --warmup 3 > gpurun_out/shares/n${n}_f$f.json 2> gpurun_out/shares/n${n}_f$f.err || { echo FAIL $n $f; tail -3 gpurun_out/shares/n${n}_f$f.err; exit 1; }
