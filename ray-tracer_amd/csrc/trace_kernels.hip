@@ -445,7 +445,10 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
 // waiting for the other 63 (rays differ several-fold in length; batch-at-a-time left 5 of 6 lanes
 // idle).  A lane is therefore a small state machine: {ray, current object k, cursor `cur`, stack
 // depth, best of object k, best of the scene}.  All objects share one node array and one slot array
-// (links are absolute), so lanes of one wave may be inside different objects.
+// (links are absolute), so lanes of one wave may be inside different objects.  In scenes of small leaves
+// the machine has two sides -- `cur` walks the nodes while `lf` tests a leaf's faces, both in the same
+// trip ("two sides" below); in scenes whose leaves hold tens of faces there is one cursor and the WAVE
+// tests a leaf's chunk ("burst").
 //
 // The queue is cut into 8 contiguous ranges with one cursor each; a wave starts on range
 // blockIdx % 8 (workgroups b and b + 8 share an XCD, hence an L2) and moves on to the next range
