@@ -489,6 +489,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_LEAF_BATCH
 #define WALK_LEAF_BATCH 2
 #endif
+#ifndef WALK_TAIL_STEAL_MIN
+#define WALK_TAIL_STEAL_MIN 24   // (with the two-sided trip a steal round costs more than the few thieves of a nearly busy wave gain: bench frame 3.47 ms at 1, 3.38 at 8, 3.33 at 16, 3.25 at 24, 3.32 at 32, 3.29 with no stealing at all)
+#endif
 #ifndef WALK_SIDE_MIN
 #define WALK_SIDE_MIN 12   // (measured flat from 1 to 28 on the bench frame)
 #endif
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
    // tuned; as constants they cost no scalar registers (the kernel is short of them: it spills scalars into vector lanes).
    constexpr int REFILL_MIN = CLOSEST ? WALK_REFILL_MIN : 64;   // refill once this many lanes are idle (or all of them); shadow waves refill whole
    constexpr int STEAL_MIN = CLOSEST ? 32 : 64;      // while the queue still has rays: steal once this many lanes are idle
-   constexpr int TAIL_STEAL_MIN = 1;                 // once the queue is dry: steal with this many idle lanes
+   constexpr int TAIL_STEAL_MIN = WALK_TAIL_STEAL_MIN;                // once the queue is dry: steal with this many idle lanes
    constexpr int AGE_MIN = 8;                        // shadow modes: idle lanes help a ray that has been walked for this many trips at once
    constexpr int SIDE_MIN = WALK_SIDE_MIN;           // two-sided trip: a side with fewer lanes than this sits the trip out, unless the other does
    constexpr int RESOLVE_MIN = CLOSEST ? WALK_RESOLVE_MIN : 1;   // faces that passed the triangle tests wait until this many lanes hold one
