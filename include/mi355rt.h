@@ -21,10 +21,12 @@
 extern "C" {
 #endif
 
-#define MI355RT_ABI_VERSION 7   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
+#define MI355RT_ABI_VERSION 8   /* 2: mi355rt_scene_create_objects, analytic objects, refraction / checkerboard materials; 3: mi355rt_host_alloc / _free;
                                  * 4: mi355rt_render_device_noalloc; 5: mi355rt_render returns hit_obj, mi355rt_mesh_desc.compute_kdtree;
                                  * 6: mi355rt_settings.tile_compact, mi355rt_tiles_unpack_device;
-                                 * 7: mi355rt_scene_view */
+                                 * 7: mi355rt_scene_view;
+                                 * 8: mi355rt_scene_set_devices / mi355rt_scene_multi_info (several GPUs behind one handle), mi355rt_render_host
+                                 *    (8-bit image as a host output), mi355rt_debug_switch, mi355rt_tiles_unpack_device writes argb8 */
 
 enum {
    MI355RT_OK = 0,
@@ -194,6 +196,36 @@ void mi355rt_scene_destroy(mi355rt_scene *scene);
  * one scene is not thread safe. */
 int mi355rt_scene_view(mi355rt_scene *scene, mi355rt_scene **view_out);
 
+/* Several GPUs behind ONE handle.  The reference's fan-out is inside the one call: Camera.createImage() scatters the pixels
+ * over availableProcessors() threads that share the read-only scene (Camera.java:129-182).  Here: give the scene a device
+ * list once, and every later mi355rt_render / mi355rt_render_host / mi355rt_render_device on it (and on views created
+ * afterwards) spreads the frame over those GPUs -- the scene's arrays are copied to each device (nothing is rebuilt), rank r
+ * (the r-th device of the list; one host thread and one stream per device inside the library) renders the tiles t with
+ * t % n_devices == r (settings.tile_size squares, 16 by default) into one tile-compact block, the blocks travel to
+ * devices[0] in the frame's one exchange step -- RCCL ncclSend / ncclRecv over xGMI (librccl.so.1 is loaded on first use),
+ * or peer copies when a device is named twice, librccl is missing or the switch MI355RT_TRANSPORT=peer is set -- and one
+ * kernel there writes the frame in image order.  Frames are bit-identical to the one-GPU frame's.
+ * devices[0] must be the scene's own device (or -1 for it); a device may appear several times (each entry is a rank with a
+ * replica and a stream of its own: how the path is rehearsed on one GPU).  Call it after mi355rt_brdf_tables and before
+ * mi355rt_scene_view, once per scene.  settings.tile_rank / tile_world / tile_compact must be unset on such a scene (the
+ * library shards the frame itself); mi355rt_frame_stats sums the ranks' counts; mi355rt_kernel_profile, mi355rt_trace_rays
+ * and mi355rt_render_device_noalloc use devices[0] alone.  mi355rt_render_device stays asynchronous on hip_stream (a stream
+ * of devices[0]): the ranks' streams wait for it, and it waits for the unpacked frame. */
+#define MI355RT_MAX_RANKS 16
+int mi355rt_scene_set_devices(mi355rt_scene *scene, const int32_t *devices, int32_t n_devices);
+
+enum { MI355RT_TRANSPORT_NONE = 0,   /* one GPU: no exchange step */
+       MI355RT_TRANSPORT_PEER = 1,   /* hipMemcpyPeerAsync from each rank's stream */
+       MI355RT_TRANSPORT_RCCL = 2 }; /* ncclSend / ncclRecv */
+typedef struct {
+   int32_t n_ranks;
+   int32_t transport;                     /* MI355RT_TRANSPORT_* */
+   int32_t devices[MI355RT_MAX_RANKS];
+   float render_ms[MI355RT_MAX_RANKS];    /* each rank's kernels of the most recent frame (HIP events on the rank's stream) */
+} mi355rt_multi_info;
+/* Blocking (waits for the most recent frame's events).  No counterpart in the reference: it is what bench.py reports per rank. */
+int mi355rt_scene_multi_info(mi355rt_scene *scene, mi355rt_multi_info *out);
+
 /* Replaces BRDFMaterial.brdfDirections / brdfWeights (materials/BRDFMaterial.java:33,43): takes the
  * PARSED tables (rows of table.txt: theta_v phi_v theta_i phi_i; rows of abrdf.dat) and applies
  * BRDFMaterial.remapDirections (:148-156, PBRTMath.java:74-97). */
@@ -225,6 +257,19 @@ int mi355rt_camera_setup(const mi355rt_scene *scene, const float orientation_deg
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
                    int32_t *hit_id_out, int32_t *hit_obj_out, float *hit_w_out);
 
+/* The same call with the 8-bit image among its host outputs: argb8 = Camera.image, W*H Color.getRGB() values written by the
+ * frame's own kernels (Camera.setPixel, Camera.java:103-107) -- a third of the bytes of rgb across PCIe, and what a caller
+ * that only displays the frame needs.  Any pointer may be NULL; only what is asked for is written on the device and copied
+ * (the copies queue behind the frame and the host waits once). */
+typedef struct {
+   float *rgb;        /* W*H*3 */
+   uint32_t *argb8;   /* W*H */
+   int32_t *hit_id;   /* W*H */
+   int32_t *hit_obj;  /* W*H */
+   float *hit_w;      /* W*H */
+} mi355rt_host_frame;
+int mi355rt_render_host(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_host_frame *out);
+
 /* Page-locked host memory for the buffers mi355rt_render writes to: its device-to-host copies then run at PCIe
  * speed instead of through the runtime's staging buffers (figures in DESIGN.md section 5).  No counterpart in the
  * reference, which has no device: it is for hosts that keep one output buffer per camera, as Camera.pixels is one
@@ -236,12 +281,14 @@ int mi355rt_host_free(void *ptr);
 /* Same frame, outputs left in device memory (pointers in `frame` are device pointers on the
  * scene's device).  Asynchronous on `hip_stream` (a hipStream_t, NULL = the null stream); the
  * caller synchronises.  With tile_world > 1 only this rank's tiles are written.
- * The call BLOCKS the host (it is still ordered on hip_stream) in three cases: the scene holds a ReflectionMaterial
- * or RefractionMaterial (one 32-byte read-back of the bounce queue's size per bounce decides whether another bounce
- * launch follows); settings.collect_stats has MI355RT_COLLECT_COUNTS / _DIAG (one read-back of the counters per
- * pass); and a call that needs more frame scratch than the scene holds so far (the first one, or a larger frame)
- * frees and allocates device memory, which synchronises the device.  Mesh-only Phong / plain frames of a size the
- * scene has rendered before return at once: that is what frames in flight on several streams rely on.
+ * The call BLOCKS the host (it is still ordered on hip_stream) in three cases: the scene holds TWO OR MORE objects with a
+ * ReflectionMaterial or RefractionMaterial and a path bounces between them more than three times (the first three bounces
+ * are enqueued without asking -- their launches find the bounce queue's size on the device; from the fourth on one 32-byte
+ * read-back per bounce tells the host when to stop.  A scene with ONE such object never blocks: a bounce ray skips the object
+ * it left, ReflectionMaterial.java:16, so its chains are one bounce long); settings.collect_stats has MI355RT_COLLECT_COUNTS /
+ * _DIAG (one read-back of the counters per pass); and a call that needs more frame scratch than the scene holds so far (the
+ * first one, or a larger frame) frees and allocates device memory, which synchronises the device.  Frames of a size the scene
+ * has rendered before return at once: that is what frames in flight on several streams rely on.
  * Frame scratch: about 104 bytes per sample slot of a pass (204 with a mirror, 348 with refraction), a pass being the
  * whole frame up to 2^27 slots -- a 3840x2160 frame at 16 spp is one pass and 14 GB -- or less when that would take
  * over a quarter of the device memory that is free when the scratch has to grow (MI355RT_PASS_SLOTS_LOG2 forces a
@@ -258,7 +305,8 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
  * ReflectionMaterial in the scene, 348 with a RefractionMaterial): 1,288,000 slots for a mesh-only scene, e.g.
  * 1280x960 at 1 spp or 640x480 at 4 spp; anything larger fails with MI355RT_E_LIMIT and changes nothing.
  * settings.collect_stats must be 0.  Inputs and outputs are as for mi355rt_render_device (device pointers in `frame`,
- * asynchronous on hip_stream unless the scene has mirrors or refraction, whose bounce loop reads a queue size back).
+ * asynchronous on hip_stream except for bounce chains longer than three, as there; NOT capturable into a HIP graph when
+ * the scene holds two or more mirror / refraction objects, whose bounce loop may synchronise the stream).
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads, two
  * scenes) race; calls in sequence on one stream are safe, whatever the previous call left behind. */
 #define MI355RT_NOALLOC_SCRATCH_BYTES (128u << 20)
@@ -270,7 +318,7 @@ int mi355rt_render_device_noalloc(mi355rt_scene *scene, const mi355rt_camera *ca
  * laid out [rgb: 3 n][hit_id: n][hit_obj: n][hit_w: n] (mi355rt_frame pointers at those offsets; slots_per_rank =
  * ceil(number of tiles / world), the same on every rank); the blocks are gathered to one rank (RCCL); this call, on that
  * rank, scatters `world` consecutive blocks at blocks_dev back into image order.  Device pointers on the current
- * device, asynchronous on hip_stream; any pointer of `frame` may be NULL (argb8 is not produced). */
+ * device, asynchronous on hip_stream; any pointer of `frame` may be NULL (argb8 is packed from the blocks' rgb). */
 int mi355rt_tiles_unpack_device(const float *blocks_dev, int32_t world, int32_t slots_per_rank, int32_t tile_size, int32_t width,
                                 int32_t height, const mi355rt_frame *frame, void *hip_stream);
 
@@ -337,6 +385,14 @@ int mi355rt_debug_scene_layout(mi355rt_scene *scene, uint64_t out[8]);
  * show that the GPU builder and the host builder (environment MI355RT_BUILDER=host) produce the same bytes.
  * No counterpart in the reference. */
 int mi355rt_debug_scene_digest(mi355rt_scene *scene, uint64_t out[4]);
+
+/* Diagnostic / tests: the library's tuning switches.  They are read from the MI355RT_* environment variables ONCE, when the
+ * library first needs one (never on the frame path, and never again: a host that calls setenv later changes nothing);
+ * this call sets one afterwards.  name: with or without the MI355RT_ prefix (BUILDER, FUSE_SHADOW, PASS_SLOTS_LOG2,
+ * BIG_LEAVES, BLOCKS_PER_CU[_SHADOW], TRIM, TRIM_PRIMARY_X2, TRIM_SHADOW_X2, SPREAD_SL, SPREAD_BL, SPREAD_PRIMARY_MAX,
+ * TRANSPORT, BOUNCE_SYNC, GPU_GROUP, BUILD_TIMING); value NULL = the built-in default; name NULL = every switch back to what
+ * the environment said.  Not for use while another thread renders.  No counterpart in the reference. */
+int mi355rt_debug_switch(const char *name, const char *value);
 
 const char *mi355rt_last_error(void);
 int mi355rt_abi_version(void);

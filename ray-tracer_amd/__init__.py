@@ -9,8 +9,8 @@ torch.distributed (tiles.py).  The directory name is not a Python identifier; im
 from . import _abi, meshgen  # noqa: F401
 from .host import (BRDFMaterial, Camera, CheckerboardMaterial, ColorInformation, Light, LightingModel,  # noqa: F401
                    PhongLightingModel, Plane, ReflectionMaterial, RefractionMaterial, RTStatics, Scene, Sphere,
-                   TriangleMesh, compute_normals, load_ply)
+                   TriangleMesh, compute_normals, debug_switch, load_ply)
 
 __all__ = ["BRDFMaterial", "Camera", "CheckerboardMaterial", "ColorInformation", "Light", "LightingModel",
            "PhongLightingModel", "Plane", "ReflectionMaterial", "RefractionMaterial", "RTStatics", "Scene", "Sphere",
-           "TriangleMesh", "compute_normals", "load_ply", "meshgen"]
+           "TriangleMesh", "compute_normals", "debug_switch", "load_ply", "meshgen"]

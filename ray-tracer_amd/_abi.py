@@ -80,6 +80,18 @@ class KernelProfile(C.Structure):
                 ("box_tests", C.c_uint64 * N_KERNELS), ("tri_tests", C.c_uint64 * N_KERNELS)]
 
 
+class HostFrame(C.Structure):
+    _fields_ = [("rgb", c_float_p), ("argb8", c_uint32_p), ("hit_id", c_int32_p), ("hit_obj", c_int32_p), ("hit_w", c_float_p)]
+
+
+MAX_RANKS = 16
+TRANSPORT_NAMES = ("none", "peer", "rccl")
+
+
+class MultiInfo(C.Structure):
+    _fields_ = [("n_ranks", C.c_int32), ("transport", C.c_int32), ("devices", C.c_int32 * MAX_RANKS), ("render_ms", C.c_float * MAX_RANKS)]
+
+
 class Frame(C.Structure):
     _fields_ = [("rgb", C.c_void_p), ("argb8", C.c_void_p), ("hit_id", C.c_void_p),
                 ("hit_obj", C.c_void_p), ("hit_w", C.c_void_p)]
@@ -91,6 +103,10 @@ PROTOTYPES = {
     "mi355rt_scene_create_objects": (C.c_int, [C.POINTER(ObjectDesc), C.c_uint32, C.POINTER(BuildOpts), C.POINTER(C.c_void_p)]),
     "mi355rt_scene_destroy": (None, [C.c_void_p]),
     "mi355rt_scene_view": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mi355rt_scene_set_devices": (C.c_int, [C.c_void_p, c_int32_p, C.c_int32]),
+    "mi355rt_scene_multi_info": (C.c_int, [C.c_void_p, C.POINTER(MultiInfo)]),
+    "mi355rt_debug_switch": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "mi355rt_render_host": (C.c_int, [C.c_void_p, C.POINTER(CameraDesc), C.POINTER(Settings), C.POINTER(HostFrame)]),
     "mi355rt_debug_scene_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mi355rt_brdf_tables": (C.c_int, [C.c_void_p, c_float_p, C.c_int32, c_float_p, C.c_int32]),
     "mi355rt_scene_epsilon": (C.c_int, [C.c_void_p, c_float_p]),

@@ -1,6 +1,8 @@
 // api.cpp -- the C ABI of libmi355rt.so (include/mi355rt.h): handles, error reporting, host-side
 // set-up (camera constants, BRDF table remap) and HIP memory / launch plumbing.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: librccl.so is loaded on demand (multi_gpu.inl), never linked
 
 #include <algorithm>
 #include <cmath>
@@ -8,11 +10,14 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mi355rt.h"
@@ -22,6 +27,7 @@
 #include "layout.h"
 #include "ply_reader.hpp"
 #include "scene_build.hpp"
+#include "switches.hpp"
 
 using namespace mi355rt;
 
@@ -149,6 +155,10 @@ struct FrameScratch {
    uint64_t bytes = 0;
 };
 
+namespace {
+struct Multi;   // multi_gpu.inl
+}
+
 struct mi355rt_scene {
    int device = 0;
    int n_cus = 256;
@@ -194,7 +204,11 @@ struct mi355rt_scene {
    int32_t *d_hit_id = nullptr;
    int32_t *d_hit_obj = nullptr;
    float *d_hit_w = nullptr;
+   uint32_t *d_argb8 = nullptr;
    size_t frame_pixels = 0;
+   hipStream_t copy_stream = nullptr;   // mi355rt_render_host: device-to-host copies run beside each other
+   int n_bouncing = 0;                  // objects with a ReflectionMaterial or RefractionMaterial
+   Multi *multi = nullptr;             // several GPUs behind this handle (mi355rt_scene_set_devices)
    // mi355rt_scene_view: a view shares the scene arrays of `parent` (everything a frame only reads) and owns what a frame
    // writes (scratch, counters, read-back block, statistics, timers, host-render frame buffers)
    mi355rt_scene *parent = nullptr;
@@ -213,10 +227,45 @@ void free_scratch(FrameScratch &fs)
    fs = FrameScratch();
 }
 
+// what a handle owns per FRAME (scratch queues, counters, read-back block, host-render frame buffers, timers): a view's
+// own, and a scene's too -- a scene destroyed while views are alive gives these back at once (up to 14-46 GB of scratch)
+void free_frame_resources(mi355rt_scene *s)
+{
+   if (s->d_counters) (void) hipFree(s->d_counters);
+   if (s->h_readback) (void) hipHostFree(s->h_readback);
+   if (s->d_rgb) (void) hipFree(s->d_rgb);
+   if (s->d_argb8) (void) hipFree(s->d_argb8);
+   if (s->d_hit_id) (void) hipFree(s->d_hit_id);
+   if (s->d_hit_obj) (void) hipFree(s->d_hit_obj);
+   if (s->d_hit_w) (void) hipFree(s->d_hit_w);
+   s->d_counters = nullptr;
+   s->h_readback = nullptr;
+   s->d_rgb = nullptr;
+   s->d_argb8 = nullptr;
+   s->d_hit_id = s->d_hit_obj = nullptr;
+   s->d_hit_w = nullptr;
+   s->frame_pixels = 0;
+   free_scratch(s->scratch);
+   for (const mi355rt_scene::TimedLaunch &t : s->pending_times) {
+      (void) hipEventDestroy(t.begin);
+      (void) hipEventDestroy(t.end);
+   }
+   s->pending_times.clear();
+   for (hipEvent_t e : s->event_pool) (void) hipEventDestroy(e);
+   s->event_pool.clear();
+   if (s->copy_stream) (void) hipStreamDestroy(s->copy_stream);
+   s->copy_stream = nullptr;
+}
+
+void release_multi(mi355rt_scene *s);   // the other GPUs' replicas, streams and blocks of a handle (below)
+
+// the calling thread's current device must be s->device
 void release_scene_impl(mi355rt_scene *s)
 {
    if (!s) return;
+   release_multi(s);
    if (!s->parent && s->n_views > 0) {   // its views still read the arrays: the last of them releases the scene
+      free_frame_resources(s);
       s->dying = true;
       return;
    }
@@ -231,18 +280,7 @@ void release_scene_impl(mi355rt_scene *s)
       if (s->d_brdf_dirs) (void) hipFree(s->d_brdf_dirs);
       if (s->d_brdf_weights) (void) hipFree(s->d_brdf_weights);
    }
-   if (s->d_counters) (void) hipFree(s->d_counters);
-   if (s->h_readback) (void) hipHostFree(s->h_readback);
-   if (s->d_rgb) (void) hipFree(s->d_rgb);
-   if (s->d_hit_id) (void) hipFree(s->d_hit_id);
-   if (s->d_hit_obj) (void) hipFree(s->d_hit_obj);
-   if (s->d_hit_w) (void) hipFree(s->d_hit_w);
-   free_scratch(s->scratch);
-   for (const mi355rt_scene::TimedLaunch &t : s->pending_times) {
-      (void) hipEventDestroy(t.begin);
-      (void) hipEventDestroy(t.end);
-   }
-   for (hipEvent_t e : s->event_pool) (void) hipEventDestroy(e);
+   free_frame_resources(s);
    mi355rt_scene *root = s->parent;
    delete s;
    if (root && --root->n_views == 0 && root->dying) release_scene_impl(root);
@@ -513,11 +551,8 @@ size_t scratch_bytes_per_slot(bool with_mirror, bool with_refraction)
 }
 size_t pass_slots(const mi355rt_scene *s, size_t frame_slots, bool with_mirror, bool with_refraction)
 {
-   const char *v = getenv("MI355RT_PASS_SLOTS_LOG2");   // read per frame
-   if (v && *v) {
-      const long l = atol(v);
+   if (const long l = switches().pass_slots_log2; l > 0)
       return (size_t) 1 << (l < 12 ? 12 : (l > (long) PASS_SLOTS_MAX_LOG2 ? (long) PASS_SLOTS_MAX_LOG2 : l));
-   }
    size_t slots = (size_t) 1 << PASS_SLOTS_DEFAULT_LOG2;
    const FrameScratch &fs = s->scratch;
    const bool fits = (fs.with_mirror || !with_mirror) && (fs.with_refraction || !with_refraction);
@@ -529,6 +564,7 @@ size_t pass_slots(const mi355rt_scene *s, size_t frame_slots, bool with_mirror, 
    while (slots > ((size_t) 1 << PASS_SLOTS_MIN_LOG2) && slots * scratch_bytes_per_slot(with_mirror, with_refraction) > free_b / 4) slots >>= 1;
    return slots;
 }
+constexpr int BOUNCE_UNCONDITIONAL = 3;   // bounces enqueued without a read-back of the bounce queue's size (run_frame)
 constexpr unsigned long long FUSE_MIN_SLOTS = 100000ull;   // passes of at least this many samples walk shadow rays inside the primary launch (with short passes dealt out spread the fused launch wins on every share of the bench frame measured: 8.3 / 2.1 / 1.0 / 0.26 M samples 3.69 / 1.86 / 1.18 / 0.58 ms against 4.06 / 2.06 / 1.37 / 0.72)
 
 int ensure_scratch(mi355rt_scene *s, size_t cap, bool with_mirror, bool with_refraction)
@@ -657,10 +693,10 @@ int fill_frame_args(const mi355rt_scene *s, const mi355rt_camera *cam, const mi3
    p.shadow_any_hit = shadow_any_hit_is_exact(s, st) ? 1 : 0;
    // One launch for primary and shadow rays (walk_kernel MODE_FUSED) is possible when the shadow answer is "any accepted
    // face" and the primary hit is final once the mesh walk ends (no spheres or planes to compare it with afterwards).
-   // Here: 0 never, 1 for passes long enough to gain from it (run_frame), 2 always.  MI355RT_FUSE_SHADOW=0/1 forces it.
-   const char *fuse_env = getenv("MI355RT_FUSE_SHADOW");
+   // Here: 0 never, 1 for passes long enough to gain from it (run_frame), 2 always.  The switch MI355RT_FUSE_SHADOW=0/1 forces it.
+   const int fuse_forced = switches().fuse_shadow;
    const bool can_fuse = p.shadow_any_hit && st->lighting_model == MI355RT_LIGHTING_PHONG && s->n_analytic == 0;
-   p.fused_shadow = !can_fuse || (fuse_env && fuse_env[0] == '0') ? 0 : ((fuse_env && fuse_env[0] == '1') ? 2 : 1);
+   p.fused_shadow = !can_fuse || fuse_forced == 0 ? 0 : (fuse_forced == 1 ? 2 : 1);
    p.brdf_dirs = s->d_brdf_dirs;
    p.brdf_weights = s->d_brdf_weights;
    p.n_dirs = s->n_dirs;
@@ -737,6 +773,7 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
    }
 
    const int fuse_policy = p.fused_shadow;
+   const bool bounce_sync = switches().bounce_sync != 0;
    for (long long m0 = 0; m0 < n_micro; m0 += micro_per_pass) {
       const long long m1 = std::min(n_micro, m0 + micro_per_pass);
       p.micro_begin = (int32_t) m0;
@@ -762,15 +799,26 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       }));
       HIP_TRY(timer.run(MI355RT_K_SHADE, [&] { return launch_shade(p, 0, p.rays0, p.hits0, p.hit_obj0, CNT_Q0, p.rays1[0], CNT_SEC_A, slots, s->n_cus, stream); }));
       if (s->has_mirror || s->has_refraction) {
-         // mirror / refraction bounces: ping-pong queues until one comes up empty (one 4-byte read-back per bounce)
+         // Mirror / refraction bounces: ping-pong queues until one comes up empty.  A bounce ray skips the object it left
+         // (ReflectionMaterial.java:16, RefractionMaterial.java:33: mirrorObject), so in a scene with ONE such object a chain
+         // is one bounce long and its single walk is simply enqueued.  With several, the first BOUNCE_UNCONDITIONAL bounces
+         // are enqueued without asking (every launch finds its queue's size on the device: the walker trims itself to it,
+         // shade and the analytic kernels stride over it, so a bounce that does not exist costs a few empty launches), and
+         // only chains longer than that cost one read-back of the queue's size per further bounce -- the host has to know
+         // when to stop.  (The switch MI355RT_BOUNCE_SYNC=1 asks after every bounce, as round 2 did: the tests compare.)
+         const int max_walks = s->n_bouncing <= 1 ? std::min(1, p.max_mirror_bounces) : p.max_mirror_bounces;
+         const int unconditional = bounce_sync ? 0 : (s->n_bouncing <= 1 ? 1 : BOUNCE_UNCONDITIONAL);
          int cur = 0;
-         for (int bounce = 0; bounce <= p.max_mirror_bounces; bounce++) {
-            uint32_t *n_band = (uint32_t *) s->h_readback;   // page-locked: a plain DMA, no staging buffer
-            HIP_TRY(hipMemcpyAsync(n_band, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), N_BANDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            unsigned long long n_sec = 0;
-            for (int b = 0; b < N_BANDS; b++) n_sec += n_band[b];
-            if (n_sec == 0) break;
+         for (int bounce = 0; bounce < max_walks; bounce++) {
+            unsigned long long n_sec = slots;   // sizes the launches when the queue's length stays on the device
+            if (bounce >= unconditional) {
+               uint32_t *n_band = (uint32_t *) s->h_readback;   // page-locked: a plain DMA, no staging buffer
+               HIP_TRY(hipMemcpyAsync(n_band, p.counters + (cur == 0 ? CNT_SEC_A : CNT_SEC_B), N_BANDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+               HIP_TRY(hipStreamSynchronize(stream));
+               n_sec = 0;
+               for (int b = 0; b < N_BANDS; b++) n_sec += n_band[b];
+               if (n_sec == 0) break;
+            }
             const int cur_cnt = cur == 0 ? CNT_SEC_A : CNT_SEC_B, nxt_cnt = cur == 0 ? CNT_SEC_B : CNT_SEC_A;
             if (cursor_set >= CNT_CURSOR_SETS - 1) cursor_set = 1;   // keep the last set for the shadow launch
             const int cw = next_cursor();
@@ -807,6 +855,63 @@ int run_frame(mi355rt_scene *s, FrameArgs &p, long long n_micro, bool collect_ti
       }
    }
    return MI355RT_OK;
+}
+
+#include "multi_gpu.inl"
+
+// One device's view of `root` (a scene, never a view): shares the arrays, owns what a frame writes.  root->device is current.
+int make_view(mi355rt_scene *root, mi355rt_scene **view_out)
+{
+   *view_out = nullptr;
+   mi355rt_scene *v = new mi355rt_scene(*root);   // the array pointers, sizes, objects, bounds and flags
+   v->parent = root;
+   v->n_views = 0;
+   v->dying = false;
+   v->multi = nullptr;
+   v->d_counters = nullptr;
+   v->h_readback = nullptr;
+   v->scratch = FrameScratch();
+   v->pending_times.clear();
+   v->event_pool.clear();
+   for (int k = 0; k < MI355RT_N_KERNELS; k++) {
+      v->kernel_ms[k] = 0.0;
+      v->kernel_launches[k] = 0;
+   }
+   v->stats_valid = false;
+   v->stats_accum = mi355rt_stats {};
+   v->d_rgb = nullptr;
+   v->d_argb8 = nullptr;
+   v->d_hit_id = v->d_hit_obj = nullptr;
+   v->d_hit_w = nullptr;
+   v->frame_pixels = 0;
+   v->copy_stream = nullptr;
+   v->device_bytes = 0;   // what the view itself holds
+   root->n_views++;       // from here on release_scene_impl(v) undoes everything
+   hipError_t e = hipMalloc((void **) &v->d_counters, CNT_WORDS * sizeof(uint32_t));
+   if (e == hipSuccess) e = hipHostMalloc((void **) &v->h_readback, N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
+   if (e == hipSuccess) e = hipMemset(v->d_counters, 0, CNT_WORDS * sizeof(uint32_t));
+   if (e != hipSuccess) {
+      release_scene_impl(v);
+      return hip_fail(e, "scene view");
+   }
+   v->device_bytes += CNT_WORDS * sizeof(uint32_t);
+   *view_out = v;
+   return MI355RT_OK;
+}
+
+// mi355rt_render_device's frame on whatever the handle spans: one GPU, or the GPUs of its device list
+int render_any(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_frame *frame, hipStream_t stream)
+{
+   if (scene->multi) return render_multi(scene, cam, settings, frame, stream);
+   FrameArgs p;
+   long long n_micro = 0;
+   if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
+   p.rgb = frame->rgb;
+   p.argb8 = frame->argb8;
+   p.hit_id = frame->hit_id;
+   p.hit_obj = frame->hit_obj;
+   p.hit_w = frame->hit_w;
+   return run_frame(scene, p, n_micro, (settings->collect_stats & MI355RT_COLLECT_TIMES) != 0, stream);
 }
 
 }   // namespace
@@ -880,8 +985,8 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       bool boxes_finite = true;
       std::vector<float> all_fnrm;
       size_t slot_total = 0, face_total = 0, node_total = 0, desc_total = 0, gface_total = 0;
-      const char *builder_env = getenv("MI355RT_BUILDER");   // "host": never build on the GPU (tuning / tests); default: GPU where it applies
-      const bool allow_gpu_build = !(builder_env && std::string(builder_env) == "host");
+      const Switches sw = switches();
+      const bool allow_gpu_build = !sw.builder_host;   // MI355RT_BUILDER=host: never build on the GPU (tuning / tests); default: GPU where it applies
 
       try {
          for (uint32_t i = 0; i < n_meshes; i++) {
@@ -894,6 +999,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             std::memcpy(ext.cell, od.ext.checker_cell, sizeof(ext.cell));
             if (md.material.kind == MI355RT_MAT_REFLECTION) s->has_mirror = true;
             if (md.material.kind == MI355RT_MAT_REFRACTION) s->has_refraction = true;
+            if (md.material.kind == MI355RT_MAT_REFLECTION || md.material.kind == MI355RT_MAT_REFRACTION) s->n_bouncing++;
             if (md.material.kind != MI355RT_MAT_COLOR) s->plain_materials = false;
             if (od.kind != MI355RT_OBJ_MESH) {
                const std::string err = add_analytic_object(s, od, dev_objs[i], ext);
@@ -968,7 +1074,7 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             gface_total += part.groups.gface.size();
             s->n_groups += part.groups.n_groups;
             s->n_shared_groups += part.groups.n_shared;
-            if (getenv("MI355RT_BUILD_TIMING")) {   // profiling aid
+            if (sw.build_timing) {   // profiling aid
                const auto t_end = std::chrono::steady_clock::now();
                std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + normals + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
                             gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
@@ -1055,10 +1161,10 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
          return hip_fail(e, "hipMalloc(counters)");
       }
       // set-up for mi355rt_render_device_noalloc: this device's address of the static scratch array, while the device is current
-      e = noalloc_scratch_ptr(device, &s->noalloc_scratch);
-      if (e != hipSuccess) {
-         release_scene(s);
-         return hip_fail(e, "hipGetSymbolAddress(scratch)");
+      // (a device that cannot resolve it -- too short of memory for the array -- only loses that entry point, which reports it)
+      if (noalloc_scratch_ptr(device, &s->noalloc_scratch) != hipSuccess) {
+         s->noalloc_scratch = nullptr;
+         (void) hipGetLastError();   // clear the sticky error
       }
       int cus = 0;
       if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus;
@@ -1103,36 +1209,59 @@ int mi355rt_scene_view(mi355rt_scene *scene, mi355rt_scene **view_out)
       if (root->dying) return fail(MI355RT_E_ARG, "the scene has been destroyed");
       DeviceScope scope(root->device);
       if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-      mi355rt_scene *v = new mi355rt_scene(*root);   // the array pointers, sizes, objects, bounds and flags
-      v->parent = root;
-      v->n_views = 0;
-      v->dying = false;
-      v->d_counters = nullptr;
-      v->h_readback = nullptr;
-      v->scratch = FrameScratch();
-      v->pending_times.clear();
-      v->event_pool.clear();
-      for (int k = 0; k < MI355RT_N_KERNELS; k++) {
-         v->kernel_ms[k] = 0.0;
-         v->kernel_launches[k] = 0;
+      mi355rt_scene *v = nullptr;
+      if (int rc = make_view(root, &v)) return rc;
+      if (root->multi) {   // a view of a scene with a device list spans the same devices
+         if (int rc = view_multi(root, v)) {
+            release_scene_impl(v);
+            return rc;
+         }
       }
-      v->stats_valid = false;
-      v->stats_accum = mi355rt_stats {};
-      v->d_rgb = nullptr;
-      v->d_hit_id = v->d_hit_obj = nullptr;
-      v->d_hit_w = nullptr;
-      v->frame_pixels = 0;
-      v->device_bytes = 0;   // what the view itself holds
-      root->n_views++;       // from here on release_scene_impl(v) undoes everything
-      hipError_t e = hipMalloc((void **) &v->d_counters, CNT_WORDS * sizeof(uint32_t));
-      if (e == hipSuccess) e = hipHostMalloc((void **) &v->h_readback, N_STATS * sizeof(unsigned long long), hipHostMallocDefault);
-      if (e == hipSuccess) e = hipMemset(v->d_counters, 0, CNT_WORDS * sizeof(uint32_t));
-      if (e != hipSuccess) {
-         release_scene_impl(v);
-         return hip_fail(e, "scene view");
-      }
-      v->device_bytes += CNT_WORDS * sizeof(uint32_t);
       *view_out = v;
+      return MI355RT_OK;
+   });
+}
+
+int mi355rt_scene_set_devices(mi355rt_scene *scene, const int32_t *devices, int32_t n_devices)
+{
+   return guarded([&]() -> int {
+      if (!scene || !devices) return fail(MI355RT_E_ARG, "null argument");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      return set_devices_impl(scene, devices, n_devices);
+   });
+}
+
+int mi355rt_scene_multi_info(mi355rt_scene *scene, mi355rt_multi_info *out)
+{
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      std::memset(out, 0, sizeof(*out));
+      out->n_ranks = 1;
+      out->transport = TRANSPORT_NONE;
+      out->devices[0] = scene->device;
+      const Multi *m = scene->multi;
+      if (!m) return MI355RT_OK;
+      out->n_ranks = (int32_t) m->ranks.size();
+      out->transport = m->shared->transport;
+      for (size_t r = 0; r < m->ranks.size(); r++) {
+         const RankCtx &rk = m->ranks[r];
+         out->devices[r] = rk.device;
+         if (!rk.timed) continue;
+         DeviceScope scope(rk.device);
+         float ms = 0.0f;
+         HIP_TRY(hipEventSynchronize(rk.t_end));
+         HIP_TRY(hipEventElapsedTime(&ms, rk.t_begin, rk.t_end));
+         out->render_ms[r] = ms;
+      }
+      return MI355RT_OK;
+   });
+}
+
+int mi355rt_debug_switch(const char *name, const char *value)
+{
+   return guarded([&]() -> int {
+      if (!set_switch(name, value)) return fail(MI355RT_E_ARG, std::string("unknown switch ") + (name ? name : ""));
       return MI355RT_OK;
    });
 }
@@ -1158,6 +1287,7 @@ int mi355rt_brdf_tables(mi355rt_scene *scene, const float *angles, int32_t n_dir
    return guarded([&]() -> int {
       if (!scene || !angles || !weights) return fail(MI355RT_E_ARG, "null argument");
       if (scene->parent || scene->n_views > 0) return fail(MI355RT_E_ARG, "set the BRDF tables on the scene before creating views of it");
+      if (scene->multi) return fail(MI355RT_E_ARG, "set the BRDF tables on the scene before giving it a device list (the replicas copy them)");
       if (n_dirs < 1 || n_materials < 1) return fail(MI355RT_E_ARG, "table sizes must be positive");
       DeviceScope scope(scene->device);
       if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
@@ -1268,18 +1398,10 @@ int mi355rt_render_device(mi355rt_scene *scene, const mi355rt_camera *cam, const
                           void *hip_stream)
 {
    return guarded([&]() -> int {
-      if (!scene || !frame) return fail(MI355RT_E_ARG, "null argument");
-      FrameArgs p;
-      long long n_micro = 0;
-      if (int rc = fill_frame_args(scene, cam, settings, p, n_micro)) return rc;
+      if (!scene || !frame || !settings) return fail(MI355RT_E_ARG, "null argument");
       DeviceScope scope(scene->device);
       if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-      p.rgb = frame->rgb;
-      p.argb8 = frame->argb8;
-      p.hit_id = frame->hit_id;
-      p.hit_obj = frame->hit_obj;
-      p.hit_w = frame->hit_w;
-      return run_frame(scene, p, n_micro, (settings->collect_stats & MI355RT_COLLECT_TIMES) != 0, (hipStream_t) hip_stream);
+      return render_any(scene, cam, settings, frame, (hipStream_t) hip_stream);
    });
 }
 
@@ -1354,8 +1476,57 @@ int mi355rt_tiles_unpack_device(const float *blocks_dev, int32_t world, int32_t 
       const long long tiles = (long long) ((width + tile_size - 1) / tile_size) * ((height + tile_size - 1) / tile_size);
       if ((long long) slots_per_rank != (tiles + world - 1) / world)
          return fail(MI355RT_E_ARG, "slots_per_rank must be ceil(tiles / world) = " + std::to_string((tiles + world - 1) / world));
-      HIP_TRY(launch_tiles_unpack(blocks_dev, world, slots_per_rank, tile_size, width, height, frame->rgb, frame->hit_id, frame->hit_obj,
-                                  frame->hit_w, (hipStream_t) hip_stream));
+      HIP_TRY(launch_tiles_unpack(blocks_dev, world, slots_per_rank, tile_size, width, height, frame->rgb, frame->argb8, frame->hit_id,
+                                  frame->hit_obj, frame->hit_w, (hipStream_t) hip_stream));
+      return MI355RT_OK;
+   });
+}
+
+int mi355rt_render_host(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, const mi355rt_host_frame *out)
+{
+   return guarded([&]() -> int {
+      if (!scene || !cam || !settings || !out) return fail(MI355RT_E_ARG, "null argument");
+      if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
+      if (settings->tile_compact) return fail(MI355RT_E_ARG, "tile_compact is for mi355rt_render_device (this call returns whole frames in image order)");
+      DeviceScope scope(scene->device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
+      const size_t pixels = (size_t) cam->width * (size_t) cam->height;
+      if (pixels > scene->frame_pixels) {
+         void **all[] = { (void **) &scene->d_rgb, (void **) &scene->d_argb8, (void **) &scene->d_hit_id, (void **) &scene->d_hit_obj, (void **) &scene->d_hit_w };
+         for (void **q : all) {
+            if (*q) (void) hipFree(*q);
+            *q = nullptr;
+         }
+         scene->frame_pixels = 0;
+         HIP_TRY(hipMalloc((void **) &scene->d_rgb, pixels * 3 * sizeof(float)));
+         HIP_TRY(hipMalloc((void **) &scene->d_argb8, pixels * sizeof(uint32_t)));
+         HIP_TRY(hipMalloc((void **) &scene->d_hit_id, pixels * sizeof(int32_t)));
+         HIP_TRY(hipMalloc((void **) &scene->d_hit_obj, pixels * sizeof(int32_t)));
+         HIP_TRY(hipMalloc((void **) &scene->d_hit_w, pixels * sizeof(float)));
+         scene->frame_pixels = pixels;
+      }
+      // an output nobody asked for is neither written nor copied
+      struct Out {
+         void *host, *dev;
+         size_t bytes;
+      } outs[] = { { out->rgb, scene->d_rgb, pixels * 3 * sizeof(float) },       { out->argb8, scene->d_argb8, pixels * sizeof(uint32_t) },
+                   { out->hit_id, scene->d_hit_id, pixels * sizeof(int32_t) },   { out->hit_obj, scene->d_hit_obj, pixels * sizeof(int32_t) },
+                   { out->hit_w, scene->d_hit_w, pixels * sizeof(float) } };
+      if (settings->tile_world > 1)   // tiles owned by other ranks stay zero
+         for (const Out &o : outs)
+            if (o.host) HIP_TRY(hipMemsetAsync(o.dev, 0, o.bytes, nullptr));
+      mi355rt_frame fr;
+      std::memset(&fr, 0, sizeof(fr));
+      fr.rgb = out->rgb ? scene->d_rgb : nullptr;
+      fr.argb8 = out->argb8 ? scene->d_argb8 : nullptr;
+      fr.hit_id = out->hit_id ? scene->d_hit_id : nullptr;
+      fr.hit_obj = out->hit_obj ? scene->d_hit_obj : nullptr;
+      fr.hit_w = out->hit_w ? scene->d_hit_w : nullptr;
+      if (int rc = render_any(scene, cam, settings, &fr, nullptr)) return rc;
+      // the copies queue behind the frame on the same stream, one after the other, and the host waits once
+      for (const Out &o : outs)
+         if (o.host) HIP_TRY(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, nullptr));
+      HIP_TRY(hipStreamSynchronize(nullptr));
       return MI355RT_OK;
    });
 }
@@ -1363,46 +1534,13 @@ int mi355rt_tiles_unpack_device(const float *blocks_dev, int32_t world, int32_t 
 int mi355rt_render(mi355rt_scene *scene, const mi355rt_camera *cam, const mi355rt_settings *settings, float *rgb_out,
                    int32_t *hit_id_out, int32_t *hit_obj_out, float *hit_w_out)
 {
-   return guarded([&]() -> int {
-      if (!scene || !cam || !settings) return fail(MI355RT_E_ARG, "null argument");
-      if (cam->width < 1 || cam->height < 1) return fail(MI355RT_E_ARG, "image size must be positive");
-      if (settings->tile_compact) return fail(MI355RT_E_ARG, "tile_compact is for mi355rt_render_device (this call returns whole frames in image order)");
-      DeviceScope scope(scene->device);
-      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device");
-      const size_t pixels = (size_t) cam->width * (size_t) cam->height;
-      if (pixels > scene->frame_pixels) {
-         void **all[] = { (void **) &scene->d_rgb, (void **) &scene->d_hit_id, (void **) &scene->d_hit_obj, (void **) &scene->d_hit_w };
-         for (void **q : all) {
-            if (*q) (void) hipFree(*q);
-            *q = nullptr;
-         }
-         scene->frame_pixels = 0;
-         HIP_TRY(hipMalloc((void **) &scene->d_rgb, pixels * 3 * sizeof(float)));
-         HIP_TRY(hipMalloc((void **) &scene->d_hit_id, pixels * sizeof(int32_t)));
-         HIP_TRY(hipMalloc((void **) &scene->d_hit_obj, pixels * sizeof(int32_t)));
-         HIP_TRY(hipMalloc((void **) &scene->d_hit_w, pixels * sizeof(float)));
-         scene->frame_pixels = pixels;
-      }
-      if (settings->tile_world > 1) {   // tiles owned by other ranks stay zero
-         HIP_TRY(hipMemsetAsync(scene->d_rgb, 0, pixels * 3 * sizeof(float), nullptr));
-         HIP_TRY(hipMemsetAsync(scene->d_hit_id, 0, pixels * sizeof(int32_t), nullptr));
-         HIP_TRY(hipMemsetAsync(scene->d_hit_obj, 0, pixels * sizeof(int32_t), nullptr));
-         HIP_TRY(hipMemsetAsync(scene->d_hit_w, 0, pixels * sizeof(float), nullptr));
-      }
-      mi355rt_frame fr;
-      std::memset(&fr, 0, sizeof(fr));
-      fr.rgb = rgb_out ? scene->d_rgb : nullptr;   // an output nobody asked for is not written either
-      fr.hit_id = hit_id_out ? scene->d_hit_id : nullptr;
-      fr.hit_obj = hit_obj_out ? scene->d_hit_obj : nullptr;
-      fr.hit_w = hit_w_out ? scene->d_hit_w : nullptr;
-      if (int rc = mi355rt_render_device(scene, cam, settings, &fr, nullptr)) return rc;
-      HIP_TRY(hipStreamSynchronize(nullptr));
-      if (rgb_out) HIP_TRY(hipMemcpy(rgb_out, scene->d_rgb, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
-      if (hit_id_out) HIP_TRY(hipMemcpy(hit_id_out, scene->d_hit_id, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (hit_obj_out) HIP_TRY(hipMemcpy(hit_obj_out, scene->d_hit_obj, pixels * sizeof(int32_t), hipMemcpyDeviceToHost));
-      if (hit_w_out) HIP_TRY(hipMemcpy(hit_w_out, scene->d_hit_w, pixels * sizeof(float), hipMemcpyDeviceToHost));
-      return MI355RT_OK;
-   });
+   mi355rt_host_frame out;
+   std::memset(&out, 0, sizeof(out));
+   out.rgb = rgb_out;
+   out.hit_id = hit_id_out;
+   out.hit_obj = hit_obj_out;
+   out.hit_w = hit_w_out;
+   return mi355rt_render_host(scene, cam, settings, &out);
 }
 
 int mi355rt_host_alloc(uint64_t bytes, void **ptr_out)
@@ -1430,6 +1568,17 @@ int mi355rt_frame_stats(mi355rt_scene *scene, mi355rt_stats *out)
       if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
       if (!scene->stats_valid) return fail(MI355RT_E_ARG, "no render with collect_stats has run on this scene");
       *out = scene->stats_accum;   // run_frame reads the counters back at the end of each pass
+      if (scene->multi) {          // a frame over several GPUs: every rank counted its own tiles
+         for (size_t r = 1; r < scene->multi->ranks.size(); r++) {
+            const mi355rt_stats &q = scene->multi->ranks[r].s->stats_accum;
+            out->primary_rays += q.primary_rays;
+            out->shadow_rays += q.shadow_rays;
+            out->secondary_rays += q.secondary_rays;
+            out->box_tests += q.box_tests;
+            out->tri_tests += q.tri_tests;
+            out->hits += q.hits;
+         }
+      }
       return MI355RT_OK;
    });
 }

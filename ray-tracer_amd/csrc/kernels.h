@@ -21,8 +21,8 @@ hipError_t launch_analytic_shadow(const FrameArgs &p, unsigned long long max_ite
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream);
 hipError_t launch_resolve(const FrameArgs &p, hipStream_t stream);
 hipError_t launch_image(const float *rgb, unsigned long long n_pixels, int normalized, unsigned *minmax2, unsigned *argb, int n_cus, hipStream_t stream);
-hipError_t launch_tiles_unpack(const float *all, int world, int slots_per_rank, int tile, int width, int height, float *rgb, int32_t *hit_id,
-                               int32_t *hit_obj, float *hit_w, hipStream_t stream);
+hipError_t launch_tiles_unpack(const float *all, int world, int slots_per_rank, int tile, int width, int height, float *rgb, unsigned *argb8,
+                               int32_t *hit_id, int32_t *hit_obj, float *hit_w, hipStream_t stream);
 hipError_t launch_batch_pack(const TraceBatchArgs &a, hipStream_t stream);
 hipError_t launch_batch_unpack(const TraceBatchArgs &a, hipStream_t stream);
 hipError_t launch_arith_probe(unsigned long long n, const float *a, const float *b, float *out_div, float *out_sqrt,

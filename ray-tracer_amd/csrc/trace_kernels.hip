@@ -33,6 +33,7 @@
 #include "device_util.h"
 #include "kernels.h"
 #include "layout.h"
+#include "switches.hpp"
 #include "walk_args.h"
 
 namespace mi355rt {
@@ -498,6 +499,8 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 constexpr int LEAF_BATCH = WALK_LEAF_BATCH;        // faces of a leaf tested per trip
 static_assert(LEAF_BATCH == 2, "a leaf trip fetches two faces");
 
+// static LDS of one walker workgroup: the stack, the steal list, and the waiting face's leaf and barycentrics
+constexpr int WALK_LDS_BYTES = (STACK_SLOTS + 1 + 1 + 2) * BLOCK_THREADS * 4;   // 26 KiB; six workgroups per CU: 156 of 160 KiB
 constexpr int walk_waves_per_simd(int stats, int mode, int big)
 {
    return big ? WALK_BIG_WAVES_PER_SIMD : (stats > 1 || mode == MODE_SHADOW || mode == MODE_SHADOW_ANY) ? WALK_SHADOW_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD;
@@ -510,6 +513,9 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
    __shared__ int s_list[BLOCK_THREADS];                              // per wave: compacted victim lanes
    __shared__ int s_pkey[BLOCK_THREADS];                              // per lane: the leaf descriptor its waiting face (`pend`) was met in
    __shared__ float s_puv[2 * BLOCK_THREADS];                         // two-sided form: that face's barycentrics, as the leaf step worked them out
+   // the tuning rests on this many workgroups fitting a CU's LDS: a word added above must not silently cost a wave per SIMD
+   static_assert(WALK_LDS_BYTES * (walk_waves_per_simd(STATS, MODE, BIG) * 4 / (BLOCK_THREADS / 64)) <= 160 * 1024,
+                 "the walker's workgroups per CU no longer fit 160 KB of LDS");
    const int lane = threadIdx.x & 63;
    const int wave_base = threadIdx.x & ~63;
    int *__restrict__ stack = s_stack + threadIdx.x;
@@ -1829,7 +1835,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) void image_pack_kernel(const float *
 // One thread per (rank, owned-tile slot, pixel of the tile).  Every rank's block has the same layout:
 // [rgb: 3 n][hit_id: n][hit_obj: n][hit_w: n] words with n = slots_per_rank * tile^2 (mi355rt_tiles_unpack_device).
 __global__ __launch_bounds__(BLOCK_THREADS) void tiles_unpack_kernel(const float *all, int world, int slots_per_rank, int tile, int width, int height,
-                                                                     float *rgb, int32_t *hit_id, int32_t *hit_obj, float *hit_w)
+                                                                     float *rgb, unsigned *argb8, int32_t *hit_id, int32_t *hit_obj, float *hit_w)
 {
    const long long tt = (long long) tile * tile;
    const long long n = (long long) slots_per_rank * tt;
@@ -1850,18 +1856,19 @@ __global__ __launch_bounds__(BLOCK_THREADS) void tiles_unpack_kernel(const float
       rgb[3 * pix + 1] = blk[3 * e + 1];
       rgb[3 * pix + 2] = blk[3 * e + 2];
    }
+   if (argb8) argb8[pix] = pack_color(blk[3 * e + 0], blk[3 * e + 1], blk[3 * e + 2]);   // Camera.image (Camera.java:103-107)
    if (hit_id) hit_id[pix] = __float_as_int(blk[3 * n + e]);
    if (hit_obj) hit_obj[pix] = __float_as_int(blk[4 * n + e]);
    if (hit_w) hit_w[pix] = blk[5 * n + e];
 }
 
-hipError_t launch_tiles_unpack(const float *all, int world, int slots_per_rank, int tile, int width, int height, float *rgb, int32_t *hit_id,
-                               int32_t *hit_obj, float *hit_w, hipStream_t stream)
+hipError_t launch_tiles_unpack(const float *all, int world, int slots_per_rank, int tile, int width, int height, float *rgb, unsigned *argb8,
+                               int32_t *hit_id, int32_t *hit_obj, float *hit_w, hipStream_t stream)
 {
    const unsigned long long n = (unsigned long long) slots_per_rank * tile * tile * (unsigned long long) world;
    if (!n) return hipSuccess;
    hipLaunchKernelGGL(tiles_unpack_kernel, dim3((unsigned) ((n + BLOCK_THREADS - 1) / BLOCK_THREADS)), dim3(BLOCK_THREADS), 0, stream, all, world,
-                      slots_per_rank, tile, width, height, rgb, hit_id, hit_obj, hit_w);
+                      slots_per_rank, tile, width, height, rgb, argb8, hit_id, hit_obj, hit_w);
    return hipGetLastError();
 }
 
@@ -1919,20 +1926,12 @@ namespace {
 
 unsigned blocks_for(unsigned long long n) { return (unsigned) ((n + BLOCK_THREADS - 1) / BLOCK_THREADS); }
 
-// persistent grids: enough resident waves to fill the chip, never more than the work can use
-int tunable(const char *name, int fallback)
-{
-   const char *v = getenv(name);
-   return v && *v ? atoi(v) : fallback;
-}
-
 // Workgroups per CU of a persistent launch.  Every launch ends on its longest rays, and the more waves are in
 // flight the more long rays are started late, so a short queue gets fewer waves (measured on 1/8 of the bench
 // frame: primary 1.24 ms at 3 per CU against 1.36 at 6 and 2.09 at 1; shadow 0.38 at 1 against 0.58 at 4).  The
 // queue length is only known on the device; `slots` (samples of the pass) stands in for it.
-int blocks_per_cu_for(const char *env, int n_cus, unsigned long long slots, unsigned long long slots_per_lane, int lo, int hi)
+int blocks_per_cu_for(int forced, int n_cus, unsigned long long slots, unsigned long long slots_per_lane, int lo, int hi)
 {
-   const int forced = tunable(env, 0);
    if (forced > 0) return forced;
    const unsigned long long per = (unsigned long long) n_cus * BLOCK_THREADS * slots_per_lane;
    const long long want = (long long) ((slots + per / 2) / per);
@@ -1941,7 +1940,7 @@ int blocks_per_cu_for(const char *env, int n_cus, unsigned long long slots, unsi
 
 unsigned persistent_grid(int n_cus, unsigned long long max_items, int blocks_per_cu)
 {
-   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) blocks_per_cu;   // blocks of 4 waves per CU (LDS: 25.6 KB each)
+   const unsigned long long want = (unsigned long long) n_cus * (unsigned long long) blocks_per_cu;   // blocks of 4 waves per CU (LDS: WALK_LDS_BYTES each)
    const unsigned long long need = (max_items + BLOCK_THREADS - 1) / BLOCK_THREADS;
    return (unsigned) (need < want ? (need ? need : 1ull) : want);
 }
@@ -1960,25 +1959,13 @@ unsigned bounded_grid(int n_cus, unsigned long long max_items)
 namespace {
 
 // Leaves of tens of faces (meshes of millions of faces under the reference's depth limit) take the walker's burst form.
-// MI355RT_BIG_LEAVES=0/1 forces either form (the tests run both and require identical frames).
-bool big_leaves(const SceneArgs &sc)
-{
-   const char *v = getenv("MI355RT_BIG_LEAVES");   // read per launch: the tests switch it between frames
-   return v && *v ? atoi(v) != 0 : sc.big_leaves != 0;
-}
-
-// MI355RT_WALKER=lds: the work-list walker (walk_lds.hip) instead of the lane walker below
-bool use_lds_walker()
-{
-   const char *v = getenv("MI355RT_WALKER");   // read per launch: the tests switch it between frames
-   return v && v[0] == 'l';
-}
+// The switch MI355RT_BIG_LEAVES=0/1 forces either form (the tests run both and require identical frames).
+bool big_leaves(const SceneArgs &sc, const Switches &sw) { return sw.big_leaves >= 0 ? sw.big_leaves != 0 : sc.big_leaves != 0; }
 
 template <int MODE>
-hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, hipStream_t stream, int n_cus = 0, unsigned long long max_items = 0)
+hipError_t launch_walk(const WalkArgs &a, unsigned grid, int stats_level, bool big, hipStream_t stream)
 {
-   if (use_lds_walker() && n_cus > 0) return launch_walk_lds(a, MODE, n_cus, max_items, stats_level, stream);
-   if (big_leaves(a.sc)) {   // (no diagnostics build of this form: level 2 counts as level 1)
+   if (big) {   // (no diagnostics build of this form: level 2 counts as level 1)
       if (stats_level >= 1) hipLaunchKernelGGL((walk_kernel<1, MODE, 1>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
       else hipLaunchKernelGGL((walk_kernel<0, MODE, 1>), dim3(grid), dim3(BLOCK_THREADS), 0, stream, a);
       return hipGetLastError();
@@ -2010,22 +1997,24 @@ hipError_t launch_trace(const SceneArgs &sc, const float *rays, float *hits, int
    a.cursor_index = cursor_index;
    a.band_cap = band_cap;
    a.stats = stats;
-   a.trim_unit = tunable("MI355RT_BLOCKS_PER_CU", 0) > 0 || !tunable("MI355RT_TRIM", 1) ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) tunable("MI355RT_TRIM_PRIMARY_X2", 5) / 2u;   // 2.5 rays per lane
+   const Switches sw = switches();
+   const bool big = big_leaves(sc, sw);
+   a.trim_unit = sw.blocks_per_cu > 0 || !sw.trim ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) sw.trim_primary_x2 / 2u;   // 2.5 rays per lane
    a.trim_step = (unsigned) n_cus;
    a.trim_lo = 2u;
    {   // Short passes are dealt out spread (walk_args.h).  Measured on shares of the bench frame, one frame at a time / two in
        // flight: 1.0 M samples 1.52 / 0.86 ms in order, 1.35 / 0.80 with 64 columns per 16,384 rays; 2.1 M samples 2.00 / 1.25 in
        // order, 1.75 / 1.43 with 16 per 4,096, 1.86 / 1.29 with 8 per 1,024 (balance costs coherence: what one frame gains two
        // in flight pay); 4.1 M 2.53 / 1.81 against 2.44 / 2.07; the whole 8.3 M-sample frame 3.69 / 2.99 against 3.78 / 3.38.
-      const int sl = tunable("MI355RT_SPREAD_SL", -1), bl = tunable("MI355RT_SPREAD_BL", -1);
-      const unsigned long long spread_max = (unsigned long long) tunable("MI355RT_SPREAD_PRIMARY_MAX", 3000000);
+      const int sl = sw.spread_sl, bl = sw.spread_bl;
+      const unsigned long long spread_max = (unsigned long long) (sw.spread_primary_max > 0 ? sw.spread_primary_max : 0);
       a.primary_spread = 0u;
       if (max_items < spread_max) a.primary_spread = max_items < 1500000ull ? (6u | (14u << 8)) : (3u | (10u << 8));
       if (a.primary_spread != 0u && sl >= 0 && bl >= sl && bl < 32) a.primary_spread = (unsigned) sl | ((unsigned) bl << 8);
    }
-   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU", n_cus, max_items, 5, 2, big_leaves(sc) ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD));
-   if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
-   return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, stream, n_cus, max_items);
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for(sw.blocks_per_cu, n_cus, max_items, 5, 2, big ? WALK_BIG_WAVES_PER_SIMD : WALK_WAVES_PER_SIMD));
+   if (fuse_light) return launch_walk<MODE_FUSED>(a, grid, stats ? (diag ? 2 : 1) : 0, big, stream);
+   return launch_walk<MODE_CLOSEST>(a, grid, stats ? (diag ? 2 : 1) : 0, big, stream);
 }
 
 hipError_t launch_generate(const FrameArgs &p, hipStream_t stream)
@@ -2083,14 +2072,16 @@ hipError_t launch_shadow(const FrameArgs &p, int cursor_index, unsigned long lon
    a.cursor_index = cursor_index;
    a.band_cap = p.band_cap;
    a.stats = p.stats;
-   a.trim_unit = tunable("MI355RT_BLOCKS_PER_CU_SHADOW", 0) > 0 || !tunable("MI355RT_TRIM", 1) ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) tunable("MI355RT_TRIM_SHADOW_X2", big_leaves(p.sc) ? 3 : 12) / 2u;   // 6 rays per lane; 1.5 where a ray is hundreds of triangle tests (measured: Thai- and Lucy-class)
+   const Switches sw = switches();
+   const bool big = big_leaves(p.sc, sw);
+   a.trim_unit = sw.blocks_per_cu_shadow > 0 || !sw.trim ? 0u : (unsigned) n_cus * BLOCK_THREADS * (unsigned) (sw.trim_shadow_x2 > 0 ? sw.trim_shadow_x2 : (big ? 3 : 12)) / 2u;   // 6 rays per lane; 1.5 where a ray is hundreds of triangle tests (measured: Thai- and Lucy-class)
    a.trim_step = (unsigned) n_cus;
    a.trim_lo = 1u;
    a.primary_spread = 0u;
-   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for("MI355RT_BLOCKS_PER_CU_SHADOW", n_cus, max_items, 25, 1, big_leaves(p.sc) ? WALK_BIG_WAVES_PER_SIMD : 4));
+   const unsigned grid = persistent_grid(n_cus, max_items, blocks_per_cu_for(sw.blocks_per_cu_shadow, n_cus, max_items, 25, 1, big ? WALK_BIG_WAVES_PER_SIMD : 4));
    const int level = p.stats ? (p.diag ? 2 : 1) : 0;
-   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, stream, n_cus, max_items);
-   return launch_walk<MODE_SHADOW>(a, grid, level, stream, n_cus, max_items);
+   if (p.shadow_any_hit) return launch_walk<MODE_SHADOW_ANY>(a, grid, level, big, stream);
+   return launch_walk<MODE_SHADOW>(a, grid, level, big, stream);
 }
 
 hipError_t launch_phong(const FrameArgs &p, unsigned long long max_items, int n_cus, hipStream_t stream)

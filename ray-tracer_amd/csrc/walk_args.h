@@ -1,5 +1,4 @@
-// walk_args.h -- what a walker launch is given: shared by the two walker kernels (trace_kernels.hip: one ray per lane;
-// walk_lds.hip: rays resident in LDS, work lists per phase).  Internal to libmi355rt.
+// walk_args.h -- what a walker launch is given (trace_kernels.hip).  Internal to libmi355rt.
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -34,8 +33,5 @@ struct WalkArgs {
    // wave of a 1/8 share of the bench frame took 1.0 ms, the average one 0.3).  low byte spread_log2, next byte block_log2.
    uint32_t primary_spread;
 };
-
-// walk_lds.hip: the same walks by the work-list kernel; mode = one of MODE_*, stats 0 / 1
-hipError_t launch_walk_lds(const WalkArgs &a, int mode, int n_cus, unsigned long long max_items, int stats, hipStream_t stream);
 
 }   // namespace mi355rt

@@ -275,6 +275,13 @@ class TriangleMesh:
         desc.mesh.n_faces = i.shape[0]
 
 
+def debug_switch(name=None, value=None):
+    """mi355rt_debug_switch: set one of the library's tuning switches (it reads the MI355RT_* environment once, at first
+    use); value None = the built-in default, name None = every switch back to what the environment said."""
+    lib = _abi.load()
+    _abi.check(lib.mi355rt_debug_switch(name.encode() if name is not None else None, str(value).encode() if value is not None else None))
+
+
 def load_ply(path):
     """mi355rt_ply_load: returns (vertices, indices, normals-or-None)."""
     lib = _abi.load()
@@ -337,6 +344,20 @@ class Scene:
         eps = C.c_float()
         _abi.check(self._lib.mi355rt_scene_epsilon(self._handle, C.byref(eps)))
         RTStatics.EPSILON = float(eps.value)
+
+    def setDevices(self, devices):
+        """mi355rt_scene_set_devices: every later frame of this scene is spread over these HIP devices (devices[0] = the
+        scene's own, where the frame is gathered); the reference's createImage() fan-out (Camera.java:129-182)."""
+        arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        _abi.check(self._lib.mi355rt_scene_set_devices(self._handle, arr, len(devices)))
+
+    def multi_info(self):
+        """mi355rt_scene_multi_info: ranks, transport of the exchange step, devices, each rank's kernel time of the last frame."""
+        mi = _abi.MultiInfo()
+        _abi.check(self._lib.mi355rt_scene_multi_info(self._handle, C.byref(mi)))
+        n = mi.n_ranks
+        return {"n_ranks": n, "transport": _abi.TRANSPORT_NAMES[mi.transport], "devices": list(mi.devices[:n]),
+                "render_ms": [float(x) for x in mi.render_ms[:n]]}
 
     def view(self):
         """mi355rt_scene_view: a second frame context on this scene (shared arrays in HBM, own scratch), so that frames
@@ -462,13 +483,14 @@ class Camera:
             W, H = self.screenWidth, self.screenHeight
             n = W * H
             ptr = C.c_void_p()
-            _abi.check(self._lib.mi355rt_host_alloc(n * 24, C.byref(ptr)))
+            _abi.check(self._lib.mi355rt_host_alloc(n * 28, C.byref(ptr)))
             self._pinned_ptr = ptr
-            base = (C.c_uint8 * (n * 24)).from_address(ptr.value)
+            base = (C.c_uint8 * (n * 28)).from_address(ptr.value)
             self._pinned = (np.frombuffer(base, dtype=np.float32, count=n * 3).reshape(H, W, 3),
                             np.frombuffer(base, dtype=np.int32, count=n, offset=n * 12).reshape(H, W),
                             np.frombuffer(base, dtype=np.int32, count=n, offset=n * 16).reshape(H, W),
-                            np.frombuffer(base, dtype=np.float32, count=n, offset=n * 20).reshape(H, W))
+                            np.frombuffer(base, dtype=np.float32, count=n, offset=n * 20).reshape(H, W),
+                            np.frombuffer(base, dtype=np.uint32, count=n, offset=n * 24).reshape(H, W))
 
     def __del__(self):
         try:
@@ -477,22 +499,35 @@ class Camera:
         except Exception:
             pass
 
-    def createImage(self):
+    def createImage(self, outputs=("pixels", "hit_id", "hit_obj", "hit_w")):
+        """Camera.createImage().  `outputs`: which of the frame's arrays come back to the host -- "pixels" (Camera.pixels),
+        "image" (Camera.image, 8-bit ARGB written by the frame's own kernels), "hit_id", "hit_obj", "hit_w"; the default is what
+        the parity tests compare.  Only what is asked for crosses PCIe (mi355rt_render_host)."""
         W, H = self.screenWidth, self.screenHeight
         if self._pinned:
-            rgb, hid, hobj, hw = self._pinned
+            rgb, hid, hobj, hw, img = self._pinned
         else:
-            rgb = np.empty((H, W, 3), dtype=np.float32)
-            hid = np.empty((H, W), dtype=np.int32)
-            hobj = np.empty((H, W), dtype=np.int32)
-            hw = np.empty((H, W), dtype=np.float32)
+            rgb = np.empty((H, W, 3), dtype=np.float32) if "pixels" in outputs else None
+            hid = np.empty((H, W), dtype=np.int32) if "hit_id" in outputs else None
+            hobj = np.empty((H, W), dtype=np.int32) if "hit_obj" in outputs else None
+            hw = np.empty((H, W), dtype=np.float32) if "hit_w" in outputs else None
+            img = np.empty((H, W), dtype=np.uint32) if "image" in outputs else None
         st = self.settings()
-        _abi.check(self._lib.mi355rt_render(self.scene._handle, C.byref(self._cam), C.byref(st), _fp(rgb), _ip(hid), _ip(hobj), _fp(hw)))
-        self._rgb_rows = rgb
-        self.pixels = rgb.transpose(1, 0, 2)   # [x][y][c] like Camera.pixels
-        self.hit_id = hid.T
-        self.hit_obj = hobj.T                  # index into Scene.objects (IntersectionInformation.intersectionObject), -1 = miss
-        self.hit_w = hw.T
+        hf = _abi.HostFrame(_fp(rgb) if "pixels" in outputs else None, img.ctypes.data_as(_abi.c_uint32_p) if "image" in outputs else None,
+                            _ip(hid) if "hit_id" in outputs else None, _ip(hobj) if "hit_obj" in outputs else None,
+                            _fp(hw) if "hit_w" in outputs else None)
+        _abi.check(self._lib.mi355rt_render_host(self.scene._handle, C.byref(self._cam), C.byref(st), C.byref(hf)))
+        if "pixels" in outputs:
+            self._rgb_rows = rgb
+            self.pixels = rgb.transpose(1, 0, 2)   # [x][y][c] like Camera.pixels
+        if "image" in outputs:
+            self.image = img                       # [H, W] uint32 ARGB, Camera.image
+        if "hit_id" in outputs:
+            self.hit_id = hid.T
+        if "hit_obj" in outputs:
+            self.hit_obj = hobj.T                  # index into Scene.objects (IntersectionInformation.intersectionObject), -1 = miss
+        if "hit_w" in outputs:
+            self.hit_w = hw.T
         for listener in self.listeners:   # ActionEvent id 1, "finished" (Camera.java:170-172)
             listener(self, 1, "finished")
         self.listeners = []

@@ -32,3 +32,11 @@ def orc():
 def rt():
     import ray_tracer_amd
     return ray_tracer_amd
+
+
+@pytest.fixture
+def switch(rt):
+    """Sets one of the library's tuning switches for the rest of the test (mi355rt_debug_switch: the library reads the
+    MI355RT_* environment once, so tests cannot flip them through os.environ); value None = the default."""
+    yield rt.debug_switch
+    rt.debug_switch(None, None)

@@ -42,11 +42,7 @@ def random_case(rt, seed):
     lo = (0.0, 100.0, 100.0) if kind == 0 else tuple(rs.uniform(-0.5, 0.5, 3) * scale) if kind == 1 else tuple(rs.uniform(-1.5, 1.5, 3) * scale)
     light = dict(origin=lo, emission=(0.3, 0.3, 0.3), ambient=(0.5, 0.5, 0.9))
     fuse = str(rs.choice(["0", "1", ""]))
-    saved = os.environ.get("MI355RT_FUSE_SHADOW")
-    if fuse:
-        os.environ["MI355RT_FUSE_SHADOW"] = fuse
-    else:
-        os.environ.pop("MI355RT_FUSE_SHADOW", None)
+    rt.debug_switch("FUSE_SHADOW", fuse or None)   # (the library reads the environment only once: mi355rt_debug_switch)
     try:
         pair = Pair(objs, orientation=tuple(rs.uniform(-40, 40, 3)), fov=float(rs.uniform(10, 30)), phong=bool(rs.rand() < 0.85),
                     light=light, brdf_tables=synthetic_brdf_tables(), use_kdtree=bool(rs.rand() < 0.9))
@@ -63,10 +59,7 @@ def random_case(rt, seed):
             w_equal, max_rel, n_diff)
         pair.close()
     finally:
-        if saved is None:
-            os.environ.pop("MI355RT_FUSE_SHADOW", None)
-        else:
-            os.environ["MI355RT_FUSE_SHADOW"] = saved
+        rt.debug_switch("FUSE_SHADOW", None)
     return ok, desc
 
 

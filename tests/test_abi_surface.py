@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(rt):
 
 
 def test_abi_version(rt):
-    assert rt._abi.load().mi355rt_abi_version() == 7
+    assert rt._abi.load().mi355rt_abi_version() == 8
 
 
 def test_struct_sizes_match_the_header(rt):

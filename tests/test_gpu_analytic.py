@@ -146,7 +146,7 @@ def test_analytic_errors_and_empty(rt):
     pair.close()
 
 
-def test_tile_shards_and_passes_with_analytic_objects(rt, monkeypatch):
+def test_tile_shards_and_passes_with_analytic_objects(rt, switch):
     """The analytic kernels run per queue entry, so tile sharding (multi-GPU) and multi-pass frames must not change a
     pixel: three ranks' tiles of the Whitted scene merge to the single-rank frame, and a frame of two passes equals
     the oracle's."""
@@ -172,7 +172,7 @@ def test_tile_shards_and_passes_with_analytic_objects(rt, monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(obj3, obj1) and torch.equal(w3, w1) and torch.equal(rgb3, rgb1)
     # two passes: 1920 x 1088 x 9 samples > 2^24 slots
-    monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", "24")
+    switch("PASS_SLOTS_LOG2", "24")
     cam2, ocam, ost = pair.cameras(1920, 1088, ms=9, seed=4)
     cam2.createImage()
     o = pair.oscene.render(ocam, ost, n_threads=16, pixel_stride=1)

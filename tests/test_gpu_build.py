@@ -9,13 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _scene(rt, meshes, builder, max_depth=None, max_children=None):
-    saved = os.environ.get("MI355RT_BUILDER")
     sd, sc = rt.RTStatics.MAX_DEPTH, rt.RTStatics.MAX_CHILDREN
     try:
-        if builder == "host":
-            os.environ["MI355RT_BUILDER"] = "host"
-        else:
-            os.environ.pop("MI355RT_BUILDER", None)
+        rt.debug_switch("BUILDER", "host" if builder == "host" else None)   # (the library reads the environment only once)
         if max_depth is not None:
             rt.RTStatics.MAX_DEPTH = max_depth
         if max_children is not None:
@@ -25,10 +21,7 @@ def _scene(rt, meshes, builder, max_depth=None, max_children=None):
         return rt.Scene(tms, light, (0, 0, 0), rt.LightingModel(), 15.0)
     finally:
         rt.RTStatics.MAX_DEPTH, rt.RTStatics.MAX_CHILDREN = sd, sc
-        if saved is None:
-            os.environ.pop("MI355RT_BUILDER", None)
-        else:
-            os.environ["MI355RT_BUILDER"] = saved
+        rt.debug_switch("BUILDER", None)
 
 
 def _same(rt, meshes, **kw):

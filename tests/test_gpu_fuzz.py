@@ -46,11 +46,11 @@ def test_random_grazing_shadow_scenes_match_the_oracle(rt, orc):
     assert not failures, "\n".join(failures)
 
 
-def test_random_scenes_match_the_oracle_in_burst_form(rt, orc, monkeypatch):
+def test_random_scenes_match_the_oracle_in_burst_form(rt, orc, switch):
     """The walker's form for leaves of tens of faces (whole chunks tested wave-wide; trace_kernels.hip "burst") forced on
     for scenes of every leaf size, hierarchy-less meshes (one leaf of many chunks) included: the same frames."""
     from fuzz_cases import random_case, random_grazing_case, random_rays_case
-    monkeypatch.setenv("MI355RT_BIG_LEAVES", "1")
+    switch("BIG_LEAVES", "1")
     failures = []
     for family, n in ((random_case, 32), (random_rays_case, 12), (random_grazing_case, 16)):
         for seed in range(100, 100 + n):

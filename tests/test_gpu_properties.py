@@ -115,11 +115,11 @@ def test_compact_blocks_unpack_to_the_whole_frame(rt):
     scene.close()
 
 
-def test_multi_pass_frame(rt, orc, monkeypatch):
+def test_multi_pass_frame(rt, orc, switch):
     """A frame of more sample slots than a pass holds runs as several passes of the pipeline (api.cpp pass_slots; the
     default pass, 2^27 slots, is forced down to 2^24 here)."""
     from helpers import compare_frames
-    monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", "24")
+    switch("PASS_SLOTS_LOG2", "24")
     scene, (v, i), cfg, light = _scene(rt, 5000, name="bunny")
     W, H, ms = 1920, 1088, 9       # 18.8 M samples -> 2 passes
     cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=3)
@@ -135,7 +135,7 @@ def test_multi_pass_frame(rt, orc, monkeypatch):
     scene.close()
 
 
-def test_frames_do_not_depend_on_the_pass_size(rt, monkeypatch):
+def test_frames_do_not_depend_on_the_pass_size(rt, switch):
     """How a frame is cut into passes is a matter of memory and speed only: a mirror over a floor rendered in passes of
     2^14, 2^17 and the default number of slots gives the same bits."""
     import torch
@@ -149,9 +149,9 @@ def test_frames_do_not_depend_on_the_pass_size(rt, monkeypatch):
     frames = []
     for log2 in ("14", "17", None):
         if log2 is None:
-            monkeypatch.delenv("MI355RT_PASS_SLOTS_LOG2", raising=False)
+            switch("PASS_SLOTS_LOG2", None)
         else:
-            monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", log2)
+            switch("PASS_SLOTS_LOG2", log2)
         f, rgb, ids, w = _device_frame(rt, cam)
         cam.render_device(f)
         torch.cuda.synchronize()
@@ -164,13 +164,13 @@ def test_frames_do_not_depend_on_the_pass_size(rt, monkeypatch):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_determinism_and_counter_identities(rt, monkeypatch, fused):
+def test_determinism_and_counter_identities(rt, switch, fused):
     """Two renders are bit-identical (whatever wave walked which ray or stole which subtree), and the
     counters obey: primary = W*H*spp, shadow = hits (one shadow ray per hit sample, RTStatics.java:617),
     per-kernel counts add up.  Both pipelines: shadow rays walked inside the primary launch (the default
     when any accepted face occludes) and in a launch of their own."""
     import torch
-    monkeypatch.setenv("MI355RT_FUSE_SHADOW", "1" if fused else "0")
+    switch("FUSE_SHADOW", "1" if fused else "0")
     scene, _, _, _ = _scene(rt, 100000)
     W, H, ms = 320, 200, 4
     cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=11)
@@ -200,7 +200,7 @@ def test_determinism_and_counter_identities(rt, monkeypatch, fused):
     scene.close()
 
 
-def test_shadow_rays_inside_the_primary_launch_equal_the_separate_launch(rt, monkeypatch):
+def test_shadow_rays_inside_the_primary_launch_equal_the_separate_launch(rt, switch):
     """MODE_FUSED (each lane walks its hit's shadow ray before it takes another primary ray) gives the frame the
     two-launch pipeline gives, bit for bit -- on a scene with two meshes, one of them a mirror (the shadow ray leaves
     the PRIMARY hit whatever the bounces find), and on the BASELINE Dragon frame."""
@@ -213,7 +213,7 @@ def test_shadow_rays_inside_the_primary_launch_equal_the_separate_launch(rt, mon
         cam = rt.Camera(scene, ms, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=5)
         frames = {}
         for fused in ("1", "0"):
-            monkeypatch.setenv("MI355RT_FUSE_SHADOW", fused)
+            switch("FUSE_SHADOW", fused)
             f, rgb, hid, hw = _device_frame(rt, cam)
             cam.render_device(f, collect_stats=True, collect_times=True)
             torch.cuda.synchronize()
@@ -386,12 +386,12 @@ def test_buddha_config_brdf_full_size(rt, orc):
     scene.close()
 
 
-def test_thai_class_mirror_4k_two_passes(rt, orc, monkeypatch):
+def test_thai_class_mirror_4k_two_passes(rt, orc, switch):
     """The shape of BASELINE configs[3]/[4] at a size the oracle can follow: a 2-million-face mesh of span 400
     (EPSILON = 1e-3, Scene.java:36) with ReflectionMaterial over a floor, 3840x2160, 3 spp = 24.9 M samples in two
     passes with mirror bounces; the oracle checks every 211th pixel."""
     from helpers import Pair
-    monkeypatch.setenv("MI355RT_PASS_SLOTS_LOG2", "24")
+    switch("PASS_SLOTS_LOG2", "24")
     v, i = rt.meshgen.blob(2000000, span=400.0, stretch=(0.59, 1.0, 0.52), seed=4)
     fv, fi = rt.meshgen.quad(-205.0, 230.0)
     pair = Pair([(v, i, None, rt.ReflectionMaterial((0.9, 0.9, 1.0))), (fv, fi, None, rt.ColorInformation((0.8, 0.3, 0.2)))],

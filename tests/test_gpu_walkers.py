@@ -1,8 +1,8 @@
 """The walker's other forms against its default form, frame for frame (bit-identical ids, objects, w and radiance):
 the burst form for leaves of tens of faces and the two-sided form for small leaves, each forced on the other's scenes
-(trace_kernels.hip, MI355RT_BIG_LEAVES=1/0), the work-list walker
-(walk_lds.hip, MI355RT_WALKER=lds), launches trimmed more or less than the default, queues dealt out
-in order or spread, and frames cut into small passes.  The oracle pins the default form elsewhere."""
+(trace_kernels.hip, switch MI355RT_BIG_LEAVES=1/0), the bounce loop with a read-back after every bounce, launches trimmed
+more or less than the default, queues dealt out in order or spread, and frames cut into small passes.  The switches are set
+through mi355rt_debug_switch (the library reads the environment only once).  The oracle pins the default form elsewhere."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -31,23 +31,22 @@ def _scenes(rt):
         yield name, rt.Scene(objs, light, (0, -25, 0), rt.PhongLightingModel(light, objs), 40.0)
 
 
-@pytest.mark.parametrize("env", [{"MI355RT_BIG_LEAVES": "1"}, {"MI355RT_WALKER": "lds"}, {"MI355RT_WALKER": "lds", "MI355RT_FUSE_SHADOW": "0"},
+@pytest.mark.parametrize("env", [{"MI355RT_BIG_LEAVES": "1"}, {"MI355RT_BOUNCE_SYNC": "1"},   # (round 2's bounce loop: a read-back after every bounce)
                                  {"MI355RT_BIG_LEAVES": "1", "MI355RT_FUSE_SHADOW": "1"},
                                  {"MI355RT_BIG_LEAVES": "0"}, {"MI355RT_BIG_LEAVES": "0", "MI355RT_FUSE_SHADOW": "1"},   # the two-sided form on leaves of many chunks too
                                  {"MI355RT_TRIM": "0"}, {"MI355RT_TRIM_PRIMARY_X2": "400", "MI355RT_TRIM_SHADOW_X2": "400"},   # launches not trimmed / trimmed to the minimum
                                  {"MI355RT_SPREAD_PRIMARY_MAX": "0"}, {"MI355RT_SPREAD_PRIMARY_MAX": "100000000", "MI355RT_SPREAD_SL": "3", "MI355RT_SPREAD_BL": "10"},   # rays taken in queue order / dealt out spread
                                  {"MI355RT_SPREAD_PRIMARY_MAX": "100000000", "MI355RT_SPREAD_SL": "5", "MI355RT_SPREAD_BL": "5"}, {"MI355RT_PASS_SLOTS_LOG2": "15"}])
-def test_other_walker_forms_render_the_same_frames(rt, monkeypatch, env):
+def test_other_walker_forms_render_the_same_frames(rt, switch, env):
     import torch
     for name, scene in _scenes(rt):
         W, H, spp = (1280, 800, 4) if "far" in name else (480, 300, 2)    # (the far-light frame is long enough for the fused launch)
-        for k in ("MI355RT_BIG_LEAVES", "MI355RT_WALKER", "MI355RT_FUSE_SHADOW", "MI355RT_TRIM", "MI355RT_TRIM_PRIMARY_X2", "MI355RT_TRIM_SHADOW_X2",
-                  "MI355RT_SPREAD_PRIMARY_MAX", "MI355RT_SPREAD_SL", "MI355RT_SPREAD_BL", "MI355RT_PASS_SLOTS_LOG2"):
-            monkeypatch.delenv(k, raising=False)
+        for k in env:
+            switch(k, None)
         ref = _frames(rt, scene, W, H, spp)
         assert int((ref[1] >= 0).sum()) > W * H // 20
         for k, val in env.items():
-            monkeypatch.setenv(k, val)
+            switch(k, val)
         got = _frames(rt, scene, W, H, spp)
         for a, b in zip(ref, got):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, env)

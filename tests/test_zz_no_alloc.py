@@ -56,6 +56,11 @@ def test_noalloc_frames_equal_render_device_frames(rt):
             torch.cuda.synchronize()
             cam.render_device_noalloc(_frame(rt, got))
             torch.cuda.synchronize()
+            # ... and the property the entry point exists for: a further call leaves the device's free memory as it was
+            free_before = torch.cuda.mem_get_info()[0]
+            cam.render_device_noalloc(_frame(rt, got))
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] == free_before, (name, W, H, spp)
             for k, (a, b) in enumerate(zip(want, got)):
                 # bit-exact, NaN-safe: compare the words
                 assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (name, W, H, spp, k)
