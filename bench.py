@@ -5,13 +5,16 @@ A "step" is one frame: every primary sample of the 1080p image, one shadow ray p
 shaded, averaged and written.  The scene (flattened hierarchy) is resident in HBM before the timed
 region; the framebuffer stays in HBM.  Rays are counted by the kernel, not assumed.
 
-N > 1 GPUs: one process per GPU.  `python bench.py --gpus N` starts the N ranks ITSELF when it was not
-started by torch.distributed.run (WORLD_SIZE unset): the parent touches no GPU, spawns N children with
-RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line and fails if any child fails -- the
-reference's own fan-out over availableProcessors() threads (Camera.java:129-182), as processes.  The
-frame's 16x16-pixel tiles are interleaved over the ranks, the scene is replicated, every rank renders
-its tiles straight into one compact block and the step ends with ONE gather of the blocks to rank 0
-over RCCL plus one unpack kernel there (strong scaling: the frame is fixed).
+N > 1 GPUs, two ways, the same tiles and the same kernels either way (the frame's 16x16-pixel tiles interleaved over the
+ranks, the scene replicated, every rank renders its tiles straight into one compact block, ONE exchange of the blocks
+to rank 0 over RCCL plus one unpack kernel there; strong scaling: the frame is fixed):
+  * `python bench.py --gpus N` (WORLD_SIZE unset): ONE process.  The scene gets the device list 0..N-1
+    (mi355rt_scene_set_devices) and every frame is one library call, as the reference's fan-out is one
+    Camera.createImage() call (Camera.java:129-182): per-device host threads, streams and the RCCL exchange are inside
+    libmi355rt.so.  This is the drop-in's own path.
+  * under torch.distributed.run (WORLD_SIZE set; the driver's launch), or with --spawn-ranks: one process per GPU over
+    torch.distributed (backend nccl = RCCL), the blocks gathered with dist.gather.  Rank 0 then also times the
+    one-process path over the same GPUs in a child process and reports it as `in_library`.
 `--dry-run-gloo` rehearses exactly that launch and exchange on CPUs (gloo, library-shaped blocks, no
 rendering): it is how the N-rank path is tested where there is no GPU.
 
@@ -72,15 +75,21 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the blocking_render and soup objects (profiling runs)")
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="tuning aid (single process): render only rank 0's tiles of an N-rank run; the line is not a bench result")
+                    help="tuning aid (one GPU): render ONE rank's tiles of an N-rank run at a time, every rank in turn; the line carries the "
+                         "per-rank times and their max (what an N-GPU frame would take before the exchange); not a bench result")
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="with --emulate-world: only this rank (-1: every rank in turn)")
+    ap.add_argument("--tile", type=int, default=0, help="tile size of the sharding (0: tiles.DEFAULT_TILE)")
+    ap.add_argument("--spawn-ranks", action="store_true", help="with --gpus N: one process per GPU over torch.distributed (the cross-check of the one-process path)")
+    ap.add_argument("--in-library-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use)")
     ap.add_argument("--frames-in-flight", type=int, default=2, help="the 'pipelined' figure: frames in flight per rank; 1 = skip")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="CPU rehearsal of the N-rank launch and exchange: gloo, library-shaped blocks, no GPU, no rendering")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
-                    help="with --gpus N: all N ranks on GPU 0, blocks exchanged over gloo through host memory -- runs the whole N-rank code "
-                         "path (tile shares, compact blocks, gather, unpack, frames in flight, frame check) where there is one GPU; not a bench result")
+                    help="with --gpus N: all N ranks on GPU 0 -- the one-process path with the device list [0] * N (peer copies), or with "
+                         "--spawn-ranks N processes whose blocks travel over gloo through host memory: the whole N-rank code path where there "
+                         "is one GPU; not a bench result")
     return ap.parse_args()
 
 
@@ -196,14 +205,39 @@ def stats_of(ms):
             "max": round(float(a.max()), 4)}
 
 
+def build_scene(rt, args, device):
+    """The workload's scene: (scene, cfg, verts, idx, normals, label, light, seconds)."""
+    cfg, verts, idx, normals, label = load_model(rt, args)
+    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))          # RayTracer.java:106
+    if args.material == "brdf":
+        from helpers import curet_tables   # tests/golden/curet_tables.npz: the reference's resources/table.txt + abrdf.dat, parsed
+        rt.BRDFMaterial.setTables(*curet_tables())
+        color = rt.BRDFMaterial(15, (0.0, 1.0, 0.0))               # RayTracer.java:162
+    else:
+        color = rt.ColorInformation((0.9, 0.9, 0.9))               # RayTracer.java:122-123
+    mesh = rt.TriangleMesh((verts, idx) if normals is None else (verts, idx, normals), color, True)
+    objects = [mesh]
+    if args.material == "mirror-floor":   # a lone mirrored mesh reflects nothing (ReflectionMaterial.java:14-24 skips the object itself)
+        fv, fi = rt.meshgen.quad(float(verts[:, 1].min()) - 0.01 * cfg["span"], 0.8 * cfg["span"])
+        objects.append(rt.TriangleMesh((fv, fi), rt.ReflectionMaterial((0.8, 0.8, 0.8)), True))
+    t0 = time.time()
+    scene = rt.Scene(objects, light, cfg["orientation"], rt.PhongLightingModel(light, objects), cfg["fov"], device=device)
+    return scene, cfg, verts, idx, normals, label, light, time.time() - t0
+
+
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    tile = args.tile or 16
+    spawn = args.spawn_ranks or args.dry_run_gloo
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and spawn:
         sys.exit(launch_ranks(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))      # torch.distributed ranks (processes)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    lib_ranks = args.gpus if world == 1 else 1           # ranks inside the library (ONE process: mi355rt_scene_set_devices)
+    if args.in_library_child:
+        world, rank, local_rank, lib_ranks = 1, 0, 0, args.gpus
+    if world > 1 and world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` or with --nproc-per-node N" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -212,6 +246,9 @@ def main():
         sys.exit(dry_run_gloo(args, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
+    if lib_ranks > 1 and not args.rehearse_one_gpu and torch.cuda.device_count() < lib_ranks:
+        raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report a %d-GPU number from fewer GPUs"
+                         % (lib_ranks, torch.cuda.device_count(), lib_ranks))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rehearse = args.rehearse_one_gpu and world > 1
@@ -227,22 +264,7 @@ def main():
     import ray_tracer_amd as rt
     from ray_tracer_amd import tiles
 
-    cfg, verts, idx, normals, label = load_model(rt, args)
-    light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))          # RayTracer.java:106
-    if args.material == "brdf":
-        from helpers import curet_tables   # tests/golden/curet_tables.npz: the reference's resources/table.txt + abrdf.dat, parsed
-        rt.BRDFMaterial.setTables(*curet_tables())
-        color = rt.BRDFMaterial(15, (0.0, 1.0, 0.0))               # RayTracer.java:162
-    else:
-        color = rt.ColorInformation((0.9, 0.9, 0.9))               # RayTracer.java:122-123
-    mesh = rt.TriangleMesh((verts, idx) if normals is None else (verts, idx, normals), color, True)
-    objects = [mesh]
-    if args.material == "mirror-floor":   # a lone mirrored mesh reflects nothing (ReflectionMaterial.java:14-24 skips the object itself)
-        fv, fi = rt.meshgen.quad(float(verts[:, 1].min()) - 0.01 * cfg["span"], 0.8 * cfg["span"])
-        objects.append(rt.TriangleMesh((fv, fi), rt.ReflectionMaterial((0.8, 0.8, 0.8)), True))
-    t0 = time.time()
-    scene = rt.Scene(objects, light, cfg["orientation"], rt.PhongLightingModel(light, objects), cfg["fov"], device=local_rank)
-    build_s = time.time() - t0
+    scene, cfg, verts, idx, normals, label, light, build_s = build_scene(rt, args, local_rank)
     W, H = args.width, args.height
     cam = rt.Camera(scene, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024)
 
@@ -251,15 +273,33 @@ def main():
     hit_obj = torch.zeros((H, W), dtype=torch.int32, device=dev)
     hit_w = torch.zeros((H, W), dtype=torch.float32, device=dev)
     frame = rt._abi.Frame(rgb.data_ptr(), None, hit_id.data_ptr(), hit_obj.data_ptr(), hit_w.data_ptr())
-    sharder = tiles.TileSharder(W, H, rank, world, tiles.DEFAULT_TILE, dev, via_host=rehearse)
     stream = torch.cuda.current_stream().cuda_stream   # the kernel is launched on torch's current stream
 
-    tile_world = args.emulate_world if (args.emulate_world > 1 and world == 1) else world
-    target = frame if world == 1 else sharder.blocks[0].frame()   # N > 1: this rank's tiles, compact, ready to send
+    if args.emulate_world > 1 and world == 1 and lib_ranks == 1:
+        print(json.dumps(emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile)))
+        return
+
+    # the frame ONE GPU renders alone: what every N-GPU frame below must equal bit for bit
+    single = None
+    if lib_ranks > 1 or (world > 1 and rank == 0):
+        single = [torch.zeros_like(t) for t in (rgb, hit_id, hit_obj, hit_w)]
+        whole = rt._abi.Frame(single[0].data_ptr(), None, single[1].data_ptr(), single[2].data_ptr(), single[3].data_ptr())
+        cam.render_device(whole, stream=stream, tile_size=tile)
+        torch.cuda.synchronize()
+    multi = None
+    if lib_ranks > 1:
+        scene.setDevices([0] * lib_ranks if args.rehearse_one_gpu else list(range(lib_ranks)))
+        multi = scene.multi_info()
+
+    sharder = tiles.TileSharder(W, H, rank, world, tile, dev, via_host=rehearse)
+    target = frame if world == 1 else sharder.blocks[0].frame()   # processes: this rank's tiles, compact, ready to send
 
     def step(stats=False, times=False):
-        cam.render_device(target, stream=stream, tile_rank=rank, tile_world=tile_world, tile_size=tiles.DEFAULT_TILE,
-                          collect_stats=stats, collect_times=times, tile_compact=world > 1)
+        if world > 1:
+            cam.render_device(target, stream=stream, tile_rank=rank, tile_world=world, tile_size=tile, collect_stats=stats, collect_times=times,
+                              tile_compact=True)
+        else:   # one GPU, or the library's own ranks behind the one call
+            cam.render_device(target, stream=stream, tile_size=tile, collect_stats=stats, collect_times=times)
 
     def exchange():
         sharder.gather(rgb, hit_id, hit_obj, hit_w)
@@ -268,7 +308,7 @@ def main():
     step(stats=True)
     torch.cuda.synchronize()
     st = cam.frame_stats()
-    kcounts = cam.kernel_profile(reset=True)   # per-walker counts of that frame
+    kcounts = cam.kernel_profile(reset=True)   # per-walker counts of that frame (the library's own ranks: rank 0's)
     counts = torch.tensor([st["primary_rays"], st["shadow_rays"], st["secondary_rays"], st["box_tests"], st["tri_tests"],
                            st["hits"]], dtype=torch.float64, device=cdev)
     local_counts = counts.clone()
@@ -288,6 +328,7 @@ def main():
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(args.steps)]
+    lib_rank_ms = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
@@ -300,11 +341,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    render_ms = [a.elapsed_time(b) for a, b, _ in ev]     # all kernels of one frame, this rank
+    render_ms = [a.elapsed_time(b) for a, b, _ in ev]     # all kernels of one frame, this rank (the library's ranks: the whole frame, exchange and unpack included)
     step_ms = [a.elapsed_time(c) for a, _, c in ev]       # with this rank's part of the exchange
     frame_ms = float(np.mean(render_ms))
     kprof = cam.kernel_profile()
     rank_ms = [frame_ms]
+    if lib_ranks > 1:
+        rank_ms = scene.multi_info()["render_ms"]          # each rank's kernels of the last frame (HIP events on the rank's stream)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -316,28 +359,25 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_per_frame / (elapsed / args.steps) / 1e6
 
-    # Not the headline: the same frames with two in flight per rank (a second scene handle, stream and block); the
+    # N > 1: the frame gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
+    frame_verified = None
+    if single is not None:
+        frame_verified = all(bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(single, (rgb, hit_id, hit_obj, hit_w)))
+
+    # Not the headline: the same frames with two in flight per rank (views of the scene on their own streams); the
     # exchange of frame k runs under the render of frame k + 1.  Every launch of the pipeline ends on its longest rays
     # with the chip draining; the next frame's bulk fills that in.  All ranks take part (the gathers are collectives).
     pipelined = None
     if args.frames_in_flight > 1:
         try:
-            pipelined = frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame, rehearse)
-        except Exception as e:   # the extra figure must not cost the run its headline line (N > 1: RCCL side streams are untested here)
+            pipelined = frames_in_flight(rt, tiles, args, scene, dev, rank, world, world, W, H, rays_per_frame, rehearse, tile)
+        except Exception as e:   # the extra figure must not cost the run its headline line
             pipelined = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.synchronize()
-
-    # N > 1: the frame rank 0 gathered from all ranks' tiles must be the frame one GPU renders alone, bit for bit
-    frame_verified = None
-    if world > 1 and rank == 0:
-        single = [torch.zeros_like(t) for t in (rgb, hit_id, hit_obj, hit_w)]
-        whole = rt._abi.Frame(single[0].data_ptr(), None, single[1].data_ptr(), single[2].data_ptr(), single[3].data_ptr())
-        cam.render_device(whole, stream=stream, tile_rank=0, tile_world=1, tile_size=tiles.DEFAULT_TILE)
-        torch.cuda.synchronize()
-        frame_verified = all(bool(torch.equal(a, b)) for a, b in zip(single, (rgb, hit_id, hit_obj, hit_w)))
-        if pipelined and "_frames_equal" in pipelined:
-            pipelined_equal = pipelined.pop("_frames_equal")(single)
-            frame_verified = frame_verified and pipelined_equal
+    if pipelined and "_frames_equal" in pipelined:
+        eq = pipelined.pop("_frames_equal")
+        if single is not None:
+            frame_verified = frame_verified and eq(single)
 
     if rank != 0:   # every collective is behind us: the rest is rank 0's bookkeeping
         if world > 1:
@@ -353,7 +393,7 @@ def main():
             v.update(rays=kcounts[name]["rays"], box_tests=kcounts[name]["box_tests"], tri_tests=kcounts[name]["tri_tests"])
     dom = max(kernels, key=lambda n: kernels[n]["ms_per_frame"])
     lp, ls, lsec, lb, lt, lh = [float(x) for x in local_counts.tolist()]
-    own_pixels = float((tiles.tile_pixels(W, H, tiles.owned_tiles(W, H, rank, tile_world, tiles.DEFAULT_TILE), tiles.DEFAULT_TILE) >= 0).sum().item())
+    own_pixels = float((tiles.tile_pixels(W, H, tiles.owned_tiles(W, H, rank, world, tile), tile) >= 0).sum().item())
     frame_bytes = BYTES_PER_BOX_TEST * lb + BYTES_PER_TRI_TEST * lt + BYTES_PER_HIT * lh + BYTES_PER_PIXEL * own_pixels
     kc = dict(kcounts[dom])
     # MODE_FUSED: the primary launch walked the shadow rays too (no shadow launch); their tests belong to it
@@ -365,26 +405,24 @@ def main():
     n_launch = max(kernels[dom]["launches_per_frame"], 1.0)
     # SURVEY.md 8(d) per-unit figures x the units one launch of that kernel processes (counted by the kernel itself
     # in the instrumented frame): child boxes tested, triangle slots tested, final hits whose normals are fetched
-    dom_hits = lh if dom == "walk_primary" else 0.0
+    dom_hits = (lh / lib_ranks) if dom == "walk_primary" else 0.0
     algo_bytes = (BYTES_PER_BOX_TEST * kc["box_tests"] + BYTES_PER_TRI_TEST * kc["tri_tests"] + BYTES_PER_HIT * dom_hits) / n_launch
     dom_ms = kernels[dom]["ms_per_launch"]
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            key = "%s_%dx%d_%dspp_n%d" % (args.model, W, H, args.spp, world)
-            traffic = tj.get(key, {}).get(dom, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    measured = measured_counters(args, W, H, world * lib_ranks, dom)
+    traffic = measured.get("hbm_bytes_per_launch")
     dom_rays = max(kc["rays"] / n_launch, 1.0)
     exact_shadow = dom == "walk_shadow" and not shadow_any_hit_proven(scene, light)
+    frac = achieved / HBM_PEAK_GBS
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(frac, 4), "traffic": traffic,
+                # What bounds the kernel in fact (profiles/, PMC): the small-leaf walker issues vector instructions 90 % of the
+                # launch at 39 % lane use; `frac` above is SURVEY 8(d)'s ALGORITHMIC bytes over time, which L2 hits let exceed
+                # what HBM moves (big-leaf scenes: even 1.0) -- the memory side's own figure is hbm_measured_frac.
+                "limiter": measured.get("limiter"), "valu_busy": measured.get("valu_busy"), "lane_util": measured.get("lane_util"),
+                "traffic_source": measured.get("source"),
                 # the memory side's own figure, from the PMC counters of profiles/ (per launch, when a profile of this workload
-                # is there): what the kernel really moves from HBM -- the rest of the algorithmic bytes are L2 / MALL hits
+                # and of these kernel sources is there): what the kernel really moves from HBM -- the rest are L2 / MALL hits
                 "hbm_measured_GBs": round(traffic / (dom_ms * 1e-3) / 1e9, 2) if traffic else None,
                 "hbm_measured_frac": round(traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "kernel": "walk_kernel<0,MODE_FUSED> (primary rays, each hit's shadow ray walked by the same lane)" if fused else
@@ -397,26 +435,37 @@ def main():
                 "tri_tests_per_ray": round(kc["tri_tests"] / n_launch / dom_rays, 2),
                 "frame": {"gpu_ms": round(frame_ms, 4), "algorithmic_bytes": frame_bytes,
                           "achieved_GBs": round(frame_bytes / (frame_ms * 1e-3) / 1e9, 2), "kernels": kernels}}
+    if frac > 1.0:
+        roofline["note"] = ("algorithmic bytes per second exceed the HBM peak: SURVEY 8(d)'s byte model counts every box and triangle test as a "
+                            "fetch, and this kernel's neighbouring rays share them in L2; not a fraction of the roofline -- see hbm_measured_frac")
 
     blocking = soup = None
-    if world == 1 and tile_world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras:
         blocking = blocking_render(rt, cam, rays_per_frame)
-        if args.model == "dragon" and not args.models_dir and args.material == "color":
+        if lib_ranks == 1 and args.model == "dragon" and not args.models_dir and args.material == "color":
             soup = soup_line(rt, args, light, cfg, dev, W, H)
 
     cpu = None
-    if not args.no_cpu_baseline and args.material == "color":
+    if not args.no_cpu_baseline and args.material == "color" and not args.in_library_child:
         cpu = cpu_baseline(args, verts, idx, normals, cfg, light)
 
+    in_library = None
+    if world > 1 and not rehearse:
+        in_library = in_library_child(args)
+
+    n_total = world * lib_ranks
     out = {
         "metric": "Mrays/sec (primary+shadow) on Dragon 1080p",
-        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "ranks": dist.get_world_size() if world > 1 else 1,
+        "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": n_total, "ranks": dist.get_world_size() if world > 1 else lib_ranks,
+        "processes": world,
         "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic" if not args.models_dir else "PLY file",
         "config": {"workload": "%s %dx%d, %d spp, Phong, primary+shadow%s" % (label, W, H, args.spp, {"color": "", "brdf": ", BRDFMaterial(15) on the CUReT tables, brdf_samples %d" % args.brdf_samples, "mirror-floor": ", over a ReflectionMaterial floor (secondary rays)"}[args.material]),
                    "rays_per_frame": int(rays_per_frame), "primary": int(primary), "shadow": int(shadow), "secondary": int(secondary),
-                   "tile": tiles.DEFAULT_TILE, "parallelism": "tiles%d" % world,
+                   "tile": tile, "parallelism": "tiles%d" % n_total,
+                   "multi_gpu_path": ("one process: mi355rt_scene_set_devices, exchange inside the library (%s)" % multi["transport"]) if lib_ranks > 1
+                                     else ("one process per GPU: torch.distributed gather (%s)" % ("gloo" if rehearse else "nccl = RCCL") if world > 1 else None),
                    "hierarchy": {k: scene.object_info(0)[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")},
                    "scene_hbm_bytes": scene.device_bytes(), "scene_build_s": round(build_s, 2)},
         # per step, from HIP events on this rank's stream: the frame's kernels alone, and with this rank's part of the exchange
@@ -424,21 +473,136 @@ def main():
         "rank_render_ms": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "all": [round(x, 4) for x in rank_ms]},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if multi:
+        out["devices"] = multi["devices"]
+        out["transport"] = multi["transport"]
     if pipelined:
         out["pipelined"] = pipelined
     if blocking:
         out["blocking_render"] = blocking
     if soup:
         out["soup"] = soup
+    if in_library:
+        out["in_library"] = in_library
     if frame_verified is not None:
         out["gathered_frame_equals_single_gpu_frame"] = frame_verified
-    if rehearse:
-        out["rehearsal"] = "all %d ranks on one GPU, blocks exchanged over gloo through host memory: the N-rank code path, not a bench result" % world
+    if args.rehearse_one_gpu and n_total > 1:
+        out["rehearsal"] = "all %d ranks on one GPU (%s): the N-rank code path, not a bench result" % (
+            n_total, "blocks exchanged over gloo through host memory" if rehearse else "device list [0] * N, peer copies")
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def in_library_child(args, limit_s=240):
+    """Under torch.distributed.run (one process per GPU) rank 0 also times the drop-in's own path -- ONE process, the device
+    list inside the library -- over the same GPUs, in a child process with a time limit (a fault or hang there must not
+    cost the run its line).  The other ranks have finished their frames; their processes only wait to exit."""
+    cmd = [sys.executable, "-u", os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--model", args.model, "--width", str(args.width), "--height", str(args.height), "--spp", str(args.spp), "--material", args.material,
+           "--no-cpu-baseline", "--no-extras", "--in-library-child"]
+    if args.faces:
+        cmd += ["--faces", str(args.faces)]
+    if args.tile:
+        cmd += ["--tile", str(args.tile)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                            "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s, text=True)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s" % limit_s}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        return {"error": "exit status %d" % r.returncode, "stderr_tail": r.stderr[-600:]}
+    j = json.loads(lines[0])
+    keep = ("value", "unit", "ms_per_step", "n_gpus", "ranks", "processes", "devices", "transport", "rank_render_ms", "step_gpu_ms",
+            "gathered_frame_equals_single_gpu_frame", "pipelined")
+    res = {k: j[k] for k in keep if k in j}
+    res["path"] = j["config"]["multi_gpu_path"]
+    return res
+
+
+def emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile):
+    """One GPU renders each rank's tiles of an N-rank frame in turn: per-rank times, their max (what the N-GPU frame takes
+    before its exchange step: the frame is done when its slowest rank is), and the same with two frames in flight."""
+    N = args.emulate_world
+    W, H = args.width, args.height
+    ranks = [args.emulate_rank] if args.emulate_rank >= 0 else list(range(N))
+    cam.render_device(frame, stream=stream, tile_size=tile, collect_stats=True)
+    torch.cuda.synchronize()
+    st = cam.frame_stats()
+    rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
+    one, rays_rank, sustained = [], [], []
+    for r in ranks:
+        cam.render_device(frame, stream=stream, tile_rank=r, tile_world=N, tile_size=tile, collect_stats=True)
+        torch.cuda.synchronize()
+        sr = cam.frame_stats()
+        rays_rank.append(int(sr["primary_rays"] + sr["shadow_rays"] + sr["secondary_rays"]))
+        for _ in range(max(2, args.warmup)):
+            cam.render_device(frame, stream=stream, tile_rank=r, tile_world=N, tile_size=tile)
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(args.steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            cam.render_device(frame, stream=stream, tile_rank=r, tile_world=N, tile_size=tile)
+            b.record()
+            torch.cuda.synchronize()   # one frame at a time
+            ms.append(a.elapsed_time(b))
+        one.append(float(np.median(ms)))
+        if args.frames_in_flight > 1:
+            D = args.frames_in_flight
+            pipe = tiles.FramePipeline(scene, lambda sc: rt.Camera(sc, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024),
+                                       W, H, r, 1, D, tile, dev, tile_world=N)
+            for _ in range(2 * D):
+                pipe.submit()
+            pipe.drain()
+            n = max(args.steps, 2 * D)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                pipe.submit()
+            pipe.drain()
+            sustained.append((time.perf_counter() - t0) / n * 1e3)
+            pipe.close()
+    res = {"emulated": True, "note": "one GPU rendering each rank's tiles of an N-rank frame in turn, before the exchange step: not a bench result",
+           "workload": "%s %dx%d, %d spp" % (label, W, H, args.spp), "world": N, "tile": tile, "ranks_measured": ranks, "rays_per_frame": int(rays),
+           "rank_rays": rays_rank, "rank_ms": [round(x, 4) for x in one], "max_ms": round(max(one), 4), "mean_ms": round(float(np.mean(one)), 4)}
+    if sustained:
+        res.update(frames_in_flight=args.frames_in_flight, rank_sustained_ms=[round(x, 4) for x in sustained], max_sustained_ms=round(max(sustained), 4))
+    return res
+
+
+def measured_counters(args, W, H, n, kernel):
+    """The PMC figures of profiles/hbm_traffic.json for this workload and kernel -- HBM bytes per launch, VALU busy, lane use --
+    when that profile was taken from the kernel sources this library was built from (their hash is in the file); else
+    nothing: the line must not carry another build's counters as this run's."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            tj = json.load(f)
+        entry = tj.get("%s_%dx%d_%dspp_n%d" % (args.model, W, H, args.spp, n), {})
+        if args.material != "color" or args.faces or args.models_dir:
+            return {}
+        if entry.get("kernel_sources_sha1") != kernel_sources_hash():
+            return {"source": "none: profiles/hbm_traffic.json was taken from other kernel sources (%s)" % str(entry.get("kernel_sources_sha1"))[:12]}
+        k = dict(entry.get(kernel, {}))
+        if k:
+            k["source"] = "profiles/hbm_traffic.json (%s; rocprofv3 --pmc passes of tools/profile_round.sh on another box, same kernel sources %s): not measured in this run" % (
+                entry.get("taken", "?"), kernel_sources_hash()[:12])
+        return k
+    except Exception:
+        return {}
+
+
+def kernel_sources_hash():
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("trace_kernels.hip", "device_util.h", "layout.h", "walk_args.h"):
+        with open(os.path.join(ROOT, "ray-tracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def shadow_any_hit_proven(scene, light):
@@ -451,14 +615,14 @@ def shadow_any_hit_proven(scene, light):
     return float(np.linalg.norm(d)) > 1.01 * diag
 
 
-def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame, via_host=False):
+def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H, rays_per_frame, via_host=False, tile=16):
     """K frames with D in flight on every rank (tiles.FramePipeline): D views of the scene (mi355rt_scene_view: shared
     arrays, own scratch) on D streams, round robin, no host sync between; with N > 1 each frame's block is gathered
     asynchronously and unpacked on rank 0 when its slot comes round again, so the exchange of frame k runs under the
     render of frame k + 1."""
     D = args.frames_in_flight
     pipe = tiles.FramePipeline(scene, lambda sc: rt.Camera(sc, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024),
-                               W, H, rank, world, D, tiles.DEFAULT_TILE, dev, tile_world=tile_world, via_host=via_host)
+                               W, H, rank, world, D, tile, dev, tile_world=tile_world, via_host=via_host)
     full = rank == 0
     for _ in range(2 * D):
         pipe.submit()
@@ -483,32 +647,38 @@ def frames_in_flight(rt, tiles, args, scene, dev, rank, world, tile_world, W, H,
     res = {"frames_in_flight": D, "steps": n, "ms_per_step": round(dt * 1e3, 4), "value": round(rays_per_frame / dt / 1e6, 2),
            "unit": "Mrays/s", "frames_identical": same, "views_of_one_scene": True,
            "note": "not the headline value: frames overlap, so a frame's launch tails (and, with N > 1, its exchange) are filled by the next frame's bulk"}
-    if world > 1 and full:
+    if full:
         keep = [t.clone() for t in outs[0]]
-        res["_frames_equal"] = lambda single: all(bool(torch.equal(a, b)) for a, b in zip(single, keep))
+        res["_frames_equal"] = lambda single: all(bool(torch.equal(a.view(torch.int32), b.view(torch.int32))) for a, b in zip(single, keep))
     pipe.close()
     return res
 
 
 def blocking_render(rt, cam, rays_per_frame, n=10):
-    """Wall time of the drop-in call itself, Camera.createImage() -> mi355rt_render: the frame's kernels, the device-to-host
-    copies of rgb / hit_id / hit_obj / hit_w into ONE page-locked set of arrays (as Camera.pixels is one array), the host
-    mirror's listener event."""
+    """Wall time of the drop-in call itself, Camera.createImage() -> mi355rt_render_host: the frame's kernels, the
+    device-to-host copies into ONE page-locked set of arrays (as Camera.pixels is one array), the host mirror's listener
+    event.  Three sets of outputs: everything the parity tests compare (rgb + hit_id + hit_obj + hit_w), Camera.pixels alone
+    (rgb), and Camera.image alone (the 8-bit ARGB image, written by the frame's own kernels: a third of rgb's bytes)."""
     cam.pinOutput(True)
+    res = {}
     try:
-        cam.createImage()
-        ms = []
-        for _ in range(n):
-            t0 = time.perf_counter()
-            cam.createImage()
-            ms.append((time.perf_counter() - t0) * 1e3)
+        for key, outputs, bpp in (("all", ("pixels", "hit_id", "hit_obj", "hit_w"), 24), ("rgb_only", ("pixels",), 12), ("argb8_only", ("image",), 4)):
+            cam.createImage(outputs=outputs)
+            ms = []
+            for _ in range(n):
+                t0 = time.perf_counter()
+                cam.createImage(outputs=outputs)
+                ms.append((time.perf_counter() - t0) * 1e3)
+            med = float(np.median(ms))
+            res[key] = {"ms": stats_of(ms), "value": round(rays_per_frame / (med * 1e-3) / 1e6, 2), "bytes_to_host": cam.screenWidth * cam.screenHeight * bpp}
     finally:
         cam.pinOutput(False)
-    med = float(np.median(ms))
-    return {"call": "mi355rt_render (blocking, host outputs rgb + hit_id + hit_obj + hit_w, page-locked)", "frames": n, "ms": stats_of(ms),
-            "value": round(rays_per_frame / (med * 1e-3) / 1e6, 2), "unit": "Mrays/s",
-            "bytes_to_host": cam.screenWidth * cam.screenHeight * 24,
-            "note": "PCIe-inclusive: never the headline value"}
+    out = {"call": "mi355rt_render_host (blocking, host outputs page-locked)", "frames": n, "unit": "Mrays/s",
+           "note": "PCIe-inclusive: never the headline value"}
+    out.update(res["all"])   # (ms / value / bytes_to_host of the full set at the top level, as in round 2's line)
+    out["rgb_only"] = res["rgb_only"]
+    out["argb8_only"] = res["argb8_only"]
+    return out
 
 
 def soup_line(rt, args, light, cfg, dev, W, H, steps=5):

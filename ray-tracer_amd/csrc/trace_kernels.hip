@@ -493,6 +493,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_TAIL_STEAL_MIN
 #define WALK_TAIL_STEAL_MIN 24   // (with the two-sided trip a steal round costs more than the few thieves of a nearly busy wave gain: bench frame 3.47 ms at 1, 3.38 at 8, 3.33 at 16, 3.25 at 24, 3.32 at 32, 3.29 with no stealing at all)
 #endif
+#ifndef WALK_NODE_REPS
+#define WALK_NODE_REPS 1
+#endif
 #ifndef WALK_SIDE_MIN
 #define WALK_SIDE_MIN 12   // (measured flat from 1 to 28 on the bench frame)
 #endif
@@ -1002,142 +1005,149 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
          // can be both).  Fetches are one after the other -- node records, then faces -- so that they share registers.
          if (STATS > 1 && st.role == ROLE_OWNER) d_ray_trips++;
          if (!CLOSEST) ++age;
-         if (lf == 0 && cur < 0) {   // the leaf side is free: the waiting leaf moves over
-            lf = cur;
-            todo = 0u;   // (one that came off the stack: its descriptor is read first)
-            if (wmask != 0u) {
-               if (((wg ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
-               gb = wg;
-               todo = wmask & ~missed;
-               if (todo == 0u && !(wg & DESC_MORE)) lf = 0;   // meanwhile the ray has missed all of its faces next door
-               wmask = 0u;
-            }
-            if (sp > bot) {
-               --sp;
-               cur = stack[sp * BLOCK_THREADS];
-            } else {
-               cur = STACK_EMPTY;
-            }
-         }
-         const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
-         const int n_node = __popcll(__ballot(in_node)), n_leaf0 = __popcll(__ballot(lf < 0));
-         const bool run_node = n_node > 0 && (exhausted || n_node >= SIDE_MIN || n_node >= n_leaf0);
-         if (run_node) {
-            const float4 *pa = nodes + NODE_F4 * (size_t) (in_node ? cur : 0);
-            const float4 na = pa[0], nb = pa[1], nc = pa[2], q3 = pa[3], q4 = pa[4];
-            const int4 nd = make_int4(__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w));
-            if (in_node) {
-               if (STATS > 1) {
-                  d_node_lane++;
-                  if (first_active_lane()) d_node_wave++;
+         // (WALK_NODE_REPS node steps per trip: a ray's chain of trips is mostly its chain of node records -- a primary ray that
+         // hits the surface tests some two hundred boxes of the reference's hierarchy, two per step)
+         bool ran_node = false;
+#pragma unroll
+         for (int rep = 0; rep < WALK_NODE_REPS; rep++) {
+            if (lf == 0 && cur < 0) {   // the leaf side is free: the waiting leaf moves over
+               lf = cur;
+               todo = 0u;   // (one that came off the stack: its descriptor is read first)
+               if (wmask != 0u) {
+                  if (((wg ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
+                  gb = wg;
+                  todo = wmask & ~missed;
+                  if (todo == 0u && !(wg & DESC_MORE)) lf = 0;   // meanwhile the ray has missed all of its faces next door
+                  wmask = 0u;
                }
-               float tl = 0.0f, tr = 0.0f;
-               bool lok = false, rok = false;
-               if (STATS) (FUSED && st.shadow ? n_box_s : n_box) += (nd.x != LINK_NONE ? 1u : 0u) + (nd.y != LINK_NONE ? 1u : 0u);
-               if (st.plain) {   // (the packed form of the step below: same arithmetic, same argument)
-                  const f2 ax = f2 { na.x, na.y } - r.o.x, ay = f2 { na.z, na.w } - r.o.y, az = f2 { nb.x, nb.y } - r.o.z;
-                  const f2 bx = f2 { nb.z, nb.w } - r.o.x, by = f2 { nc.x, nc.y } - r.o.y, bz = f2 { nc.z, nc.w } - r.o.z;
-                  const f2 t1x = ax * r.inv.x, t1y = ay * r.inv.y, t1z = az * r.inv.z;
-                  const f2 t2x = bx * r.inv.x, t2y = by * r.inv.y, t2z = bz * r.inv.z;
-                  const f2 ddx = { fmaxf(fmaxf(ax.x, -bx.x), 0.0f), fmaxf(fmaxf(ax.y, -bx.y), 0.0f) };
-                  const f2 ddy = { fmaxf(fmaxf(ay.x, -by.x), 0.0f), fmaxf(fmaxf(ay.y, -by.y), 0.0f) };
-                  const f2 ddz = { fmaxf(fmaxf(az.x, -bz.x), 0.0f), fmaxf(fmaxf(az.y, -bz.y), 0.0f) };
-                  const f2 d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                  tl = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
-                  tr = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
-                  const float hl = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
-                  const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
-                  lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
-                  rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
-                  if (MODE == MODE_SHADOW && !st.redo) {
-                     const f2 fx = { fmaxf(light.x - na.x, nb.z - light.x), fmaxf(light.x - na.y, nb.w - light.x) };
-                     const f2 fy = { fmaxf(light.y - na.z, nc.x - light.y), fmaxf(light.y - na.w, nc.y - light.y) };
-                     const f2 fz = { fmaxf(light.z - nb.x, nc.z - light.z), fmaxf(light.z - nb.y, nc.w - light.z) };
-                     const f2 far2 = (fx * fx + fy * fy + fz * fz) * 1.0001f + a.light_prune_c;
-                     lok = lok && !(d2.x > far2.x);
-                     rok = rok && !(d2.y > far2.y);
-                  }
-               } else {
-                  if (nd.x != LINK_NONE)
-                     lok = slab_test(r, nearp, farp, na.x, na.z, nb.x, nb.z, nc.x, nc.z, tl) &&
-                           !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > lim2);
-                  if (nd.y != LINK_NONE)
-                     rok = slab_test(r, nearp, farp, na.y, na.w, nb.y, nb.w, nc.y, nc.w, tr) &&
-                           !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > lim2);
-                  if (MODE == MODE_SHADOW && !st.redo && a.sc.boxes_finite) {
-                     lok = lok && !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > light_far2(light, na.x, na.z, nb.x, nb.z, nc.x, nc.z) * 1.0001f + a.light_prune_c);
-                     rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
-                  }
-               }
-               const int le = nd.z > 0 ? ~nd.x : nd.x;
-               const int re = nd.w > 0 ? ~nd.y : nd.y;
-               // what is left to test in a leaf child is known here (the leaf side's group and `missed` only ever grow
-               // while the group stays: a face in `missed` HAS missed this ray, whenever that is asked)
-               const int lg = __float_as_int(q4.x), rg = __float_as_int(q4.z);
-               const unsigned ltodo = __float_as_uint(q4.y) & ~((((lg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
-               const unsigned rtodo = __float_as_uint(q4.w) & ~((((rg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
-               if (nd.z > 0 && ltodo == 0u && !(lg & DESC_MORE)) {
-                  if (STATS > 1 && lok) d_repeat += (unsigned) __popc(__float_as_uint(q4.y));
-                  lok = false;
-               }
-               if (nd.w > 0 && rtodo == 0u && !(rg & DESC_MORE)) {
-                  if (STATS > 1 && rok) d_repeat += (unsigned) __popc(__float_as_uint(q4.w));
-                  rok = false;
-               }
-               // A leaf child goes to the leaf side if that is free (with its words: no descriptor read); the node side
-               // goes on with the other child or the stack.  A leaf child that finds the leaf side busy waits in `cur`.
-               const bool lfree = lf == 0;
-               int hand = 0;   // 1 / 2: the left / right child goes to the leaf side
-               int kept = 0;   // 1 / 2: the left / right child is what `cur` holds now
-               if (lok && rok) {
-                  const bool swap = tr < tl;   // nearest child first; the order never decides WHETHER a child is visited
-                  const int n1 = swap ? re : le, n2 = swap ? le : re;
-                  if (lfree && n1 < 0) {
-                     hand = swap ? 2 : 1;
-                     cur = n2;
-                     kept = swap ? 1 : 2;
-                  } else if (lfree && n2 < 0) {
-                     hand = swap ? 1 : 2;
-                     cur = n1;
-                     kept = swap ? 2 : 1;
-                  } else {
-                     cur = n1;
-                     kept = swap ? 2 : 1;
-                     stack[sp * BLOCK_THREADS] = n2;
-                     ++sp;
-                  }
-               } else if (lok || rok) {
-                  const int n1 = lok ? le : re;
-                  if (lfree && n1 < 0) {
-                     hand = lok ? 1 : 2;
-                     if (sp > bot) {
-                        --sp;
-                        cur = stack[sp * BLOCK_THREADS];
-                     } else {
-                        cur = STACK_EMPTY;
-                     }
-                  } else {
-                     cur = n1;
-                     kept = lok ? 1 : 2;
-                  }
-               } else if (sp > bot) {
+               if (sp > bot) {
                   --sp;
                   cur = stack[sp * BLOCK_THREADS];
                } else {
                   cur = STACK_EMPTY;
                }
-               wmask = 0u;
-               if (kept != 0 && cur < 0) {
-                  wg = kept == 1 ? lg : rg;
-                  wmask = kept == 1 ? __float_as_uint(q4.y) : __float_as_uint(q4.w);
-               }
-               if (hand != 0) {
-                  const int g = hand == 1 ? lg : rg;
-                  lf = hand == 1 ? le : re;
-                  if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
-                  if (STATS > 1) d_repeat += (unsigned) __popc((hand == 1 ? __float_as_uint(q4.y) : __float_as_uint(q4.w)) & missed);
-                  gb = g;
-                  todo = hand == 1 ? ltodo : rtodo;   // 0 only for a leaf that goes on in further descriptors: the leaf step moves on
+            }
+            const bool in_node = (unsigned) cur < (unsigned) STACK_EMPTY;
+            const int n_node = __popcll(__ballot(in_node)), n_leaf0 = __popcll(__ballot(lf < 0));
+            const bool run_node = n_node > 0 && (exhausted || n_node >= SIDE_MIN || n_node >= n_leaf0);
+            ran_node = ran_node || run_node;
+            if (run_node) {
+               const float4 *pa = nodes + NODE_F4 * (size_t) (in_node ? cur : 0);
+               const float4 na = pa[0], nb = pa[1], nc = pa[2], q3 = pa[3], q4 = pa[4];
+               const int4 nd = make_int4(__float_as_int(q3.x), __float_as_int(q3.y), __float_as_int(q3.z), __float_as_int(q3.w));
+               if (in_node) {
+                  if (STATS > 1) {
+                     d_node_lane++;
+                     if (first_active_lane()) d_node_wave++;
+                  }
+                  float tl = 0.0f, tr = 0.0f;
+                  bool lok = false, rok = false;
+                  if (STATS) (FUSED && st.shadow ? n_box_s : n_box) += (nd.x != LINK_NONE ? 1u : 0u) + (nd.y != LINK_NONE ? 1u : 0u);
+                  if (st.plain) {   // (the packed form of the step below: same arithmetic, same argument)
+                     const f2 ax = f2 { na.x, na.y } - r.o.x, ay = f2 { na.z, na.w } - r.o.y, az = f2 { nb.x, nb.y } - r.o.z;
+                     const f2 bx = f2 { nb.z, nb.w } - r.o.x, by = f2 { nc.x, nc.y } - r.o.y, bz = f2 { nc.z, nc.w } - r.o.z;
+                     const f2 t1x = ax * r.inv.x, t1y = ay * r.inv.y, t1z = az * r.inv.z;
+                     const f2 t2x = bx * r.inv.x, t2y = by * r.inv.y, t2z = bz * r.inv.z;
+                     const f2 ddx = { fmaxf(fmaxf(ax.x, -bx.x), 0.0f), fmaxf(fmaxf(ax.y, -bx.y), 0.0f) };
+                     const f2 ddy = { fmaxf(fmaxf(ay.x, -by.x), 0.0f), fmaxf(fmaxf(ay.y, -by.y), 0.0f) };
+                     const f2 ddz = { fmaxf(fmaxf(az.x, -bz.x), 0.0f), fmaxf(fmaxf(az.y, -bz.y), 0.0f) };
+                     const f2 d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+                     tl = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
+                     tr = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
+                     const float hl = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
+                     const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
+                     lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
+                     rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
+                     if (MODE == MODE_SHADOW && !st.redo) {
+                        const f2 fx = { fmaxf(light.x - na.x, nb.z - light.x), fmaxf(light.x - na.y, nb.w - light.x) };
+                        const f2 fy = { fmaxf(light.y - na.z, nc.x - light.y), fmaxf(light.y - na.w, nc.y - light.y) };
+                        const f2 fz = { fmaxf(light.z - nb.x, nc.z - light.z), fmaxf(light.z - nb.y, nc.w - light.z) };
+                        const f2 far2 = (fx * fx + fy * fy + fz * fz) * 1.0001f + a.light_prune_c;
+                        lok = lok && !(d2.x > far2.x);
+                        rok = rok && !(d2.y > far2.y);
+                     }
+                  } else {
+                     if (nd.x != LINK_NONE)
+                        lok = slab_test(r, nearp, farp, na.x, na.z, nb.x, nb.z, nc.x, nc.z, tl) &&
+                              !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > lim2);
+                     if (nd.y != LINK_NONE)
+                        rok = slab_test(r, nearp, farp, na.y, na.w, nb.y, nb.w, nc.y, nc.w, tr) &&
+                              !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > lim2);
+                     if (MODE == MODE_SHADOW && !st.redo && a.sc.boxes_finite) {
+                        lok = lok && !(origin_box_dist2(r, na.x, na.z, nb.x, nb.z, nc.x, nc.z) > light_far2(light, na.x, na.z, nb.x, nb.z, nc.x, nc.z) * 1.0001f + a.light_prune_c);
+                        rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
+                     }
+                  }
+                  const int le = nd.z > 0 ? ~nd.x : nd.x;
+                  const int re = nd.w > 0 ? ~nd.y : nd.y;
+                  // what is left to test in a leaf child is known here (the leaf side's group and `missed` only ever grow
+                  // while the group stays: a face in `missed` HAS missed this ray, whenever that is asked)
+                  const int lg = __float_as_int(q4.x), rg = __float_as_int(q4.z);
+                  const unsigned ltodo = __float_as_uint(q4.y) & ~((((lg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
+                  const unsigned rtodo = __float_as_uint(q4.w) & ~((((rg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
+                  if (nd.z > 0 && ltodo == 0u && !(lg & DESC_MORE)) {
+                     if (STATS > 1 && lok) d_repeat += (unsigned) __popc(__float_as_uint(q4.y));
+                     lok = false;
+                  }
+                  if (nd.w > 0 && rtodo == 0u && !(rg & DESC_MORE)) {
+                     if (STATS > 1 && rok) d_repeat += (unsigned) __popc(__float_as_uint(q4.w));
+                     rok = false;
+                  }
+                  // A leaf child goes to the leaf side if that is free (with its words: no descriptor read); the node side
+                  // goes on with the other child or the stack.  A leaf child that finds the leaf side busy waits in `cur`.
+                  const bool lfree = lf == 0;
+                  int hand = 0;   // 1 / 2: the left / right child goes to the leaf side
+                  int kept = 0;   // 1 / 2: the left / right child is what `cur` holds now
+                  if (lok && rok) {
+                     const bool swap = tr < tl;   // nearest child first; the order never decides WHETHER a child is visited
+                     const int n1 = swap ? re : le, n2 = swap ? le : re;
+                     if (lfree && n1 < 0) {
+                        hand = swap ? 2 : 1;
+                        cur = n2;
+                        kept = swap ? 1 : 2;
+                     } else if (lfree && n2 < 0) {
+                        hand = swap ? 1 : 2;
+                        cur = n1;
+                        kept = swap ? 2 : 1;
+                     } else {
+                        cur = n1;
+                        kept = swap ? 2 : 1;
+                        stack[sp * BLOCK_THREADS] = n2;
+                        ++sp;
+                     }
+                  } else if (lok || rok) {
+                     const int n1 = lok ? le : re;
+                     if (lfree && n1 < 0) {
+                        hand = lok ? 1 : 2;
+                        if (sp > bot) {
+                           --sp;
+                           cur = stack[sp * BLOCK_THREADS];
+                        } else {
+                           cur = STACK_EMPTY;
+                        }
+                     } else {
+                        cur = n1;
+                        kept = lok ? 1 : 2;
+                     }
+                  } else if (sp > bot) {
+                     --sp;
+                     cur = stack[sp * BLOCK_THREADS];
+                  } else {
+                     cur = STACK_EMPTY;
+                  }
+                  wmask = 0u;
+                  if (kept != 0 && cur < 0) {
+                     wg = kept == 1 ? lg : rg;
+                     wmask = kept == 1 ? __float_as_uint(q4.y) : __float_as_uint(q4.w);
+                  }
+                  if (hand != 0) {
+                     const int g = hand == 1 ? lg : rg;
+                     lf = hand == 1 ? le : re;
+                     if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
+                     if (STATS > 1) d_repeat += (unsigned) __popc((hand == 1 ? __float_as_uint(q4.y) : __float_as_uint(q4.w)) & missed);
+                     gb = g;
+                     todo = hand == 1 ? ltodo : rtodo;   // 0 only for a leaf that goes on in further descriptors: the leaf step moves on
+                  }
                }
             }
          }
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
          bool want_resolve = false;
          const bool in_leaf = lf < 0;
          const int n_leaf = __popcll(__ballot(in_leaf));
-         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= SIDE_MIN || !run_node);
+         const bool run_leaf = n_leaf > 0 && (exhausted || n_leaf >= SIDE_MIN || !ran_node);
          if (run_leaf) {
             const bool want_desc = in_leaf && todo == 0u;
             const unsigned rest0 = todo & (todo - 1u);

@@ -6,6 +6,6 @@ mkdir -p ../../build/variants
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize $flags -Rpass-analysis=kernel-resource-usage -c trace_kernels.hip -o ../../build/variants/$name.o 2> ../../build/variants/$name.txt
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/variants/$name.so api.o scene_build.o ply_reader.o walk_lds.o analytic_kernels.o gpu_build.o ../../build/variants/$name.o
-  echo "$name: $(grep -A8 'walk_kernelILi0ELi0' ../../build/variants/$name.txt | grep -E 'VGPRs:|Scratch|Occupancy' | sed 's/.*remark: *//; s/ \[.*//' | tr '\n' ' ')"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/variants/$name.so api.o switches.o scene_build.o ply_reader.o analytic_kernels.o gpu_build.o ../../build/variants/$name.o
+  echo "$name: $(grep -A8 'walk_kernelILi0ELi3ELi0' ../../build/variants/$name.txt | grep -E 'VGPRs:|Scratch|Occupancy' | sed 's/.*remark: *//; s/ \[.*//' | tr '\n' ' ')"
 done
