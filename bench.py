@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--model", default="dragon", help="stand-in from meshgen.STANFORD")
     ap.add_argument("--faces", type=int, default=0, help="override the face count (0 = the model's own)")
     ap.add_argument("--models-dir", default="", help="base dir laid out as the reference's README.txt:10-15: render the real PLY instead of the stand-in")
+    ap.add_argument("--via-ply", action="store_true",
+                    help="write the stand-in as a big-endian binary PLY (what TriangleMesh.readBinary reads) and load it back through "
+                         "mi355rt_ply_load: config.scene_create then has the parse time too")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
@@ -196,7 +199,19 @@ def load_model(rt, args):
         return cfg, v, i, n, "%s (%s)" % (args.model, path)
     v, i = rt.meshgen.stanford_standin(args.model, args.faces or None)
     label = "configs[1]: Dragon" if args.model == "dragon" and not args.faces else args.model
+    if args.via_ply:   # the loader's half of the path: TriangleMesh.readBinary's file format, parsed by the library's reader
+        path = os.path.join(tempfile.gettempdir(), "mi355rt_bench_%s_%d.ply" % (args.model, os.getpid()))
+        rt.meshgen.write_ply(path, v, i, binary=True)
+        nbytes = os.path.getsize(path)
+        t0 = time.time()
+        v, i, _ = rt.load_ply(path)
+        PLY_TIMES["ply_parse_s"] = round(time.time() - t0, 3)
+        PLY_TIMES["ply_bytes"] = nbytes
+        os.remove(path)
     return cfg, v, i, None, "%s stand-in (seeded procedural blob, %d faces)" % (label, i.shape[0])
+
+
+PLY_TIMES = {}
 
 
 def stats_of(ms):
@@ -467,7 +482,9 @@ def main():
                    "multi_gpu_path": ("one process: mi355rt_scene_set_devices, exchange inside the library (%s)" % multi["transport"]) if lib_ranks > 1
                                      else ("one process per GPU: torch.distributed gather (%s)" % ("gloo" if rehearse else "nccl = RCCL") if world > 1 else None),
                    "hierarchy": {k: scene.object_info(0)[k] for k in ("n_nodes", "n_leaves", "n_leaf_slots", "max_depth")},
-                   "scene_hbm_bytes": scene.device_bytes(), "scene_build_s": round(build_s, 2)},
+                   "scene_hbm_bytes": scene.device_bytes(), "scene_build_s": round(build_s, 2),
+                   # where Scene() spent it (mi355rt_scene_build_seconds; TriangleMesh.java:84-85,123-124 and KDTree.java:49-55 print the reference's own)
+                   "scene_create": dict(scene.build_seconds(), total_s=round(build_s, 3), **PLY_TIMES)},
         # per step, from HIP events on this rank's stream: the frame's kernels alone, and with this rank's part of the exchange
         "step_gpu_ms": {"render": stats_of(render_ms), "render_and_exchange": stats_of(step_ms)},
         "rank_render_ms": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4), "all": [round(x, 4) for x in rank_ms]},

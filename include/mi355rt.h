@@ -173,8 +173,9 @@ typedef struct mi355rt_scene mi355rt_scene;
  * (bounds/KDTree.java:24-56, bounds/KDNode.java:29-90) and `new Scene(volumes, ...)`'s bounds
  * (Scene.java:21-33): builds the reference's hierarchy, flattened, in HBM.  The hierarchy of a mesh whose root
  * splits and whose vertices are all finite is built on the GPU, level by level; any other
- * mesh, and every mesh when the environment has MI355RT_BUILDER=host, by the equivalent host builder.  Both give
- * the same bytes. */
+ * mesh, and every mesh when the switch MI355RT_BUILDER=host is set, by the equivalent host builder.  Both give the same bytes.
+ * For a mesh the GPU builder takes, the vertex normals (when the mesh brings none), the leaf groups and the node records are
+ * made on the device as well: nothing but the caller's arrays crosses PCIe. */
 int mi355rt_scene_create(const mi355rt_mesh_desc *meshes, uint32_t n_meshes, const mi355rt_build_opts *opts,
                          mi355rt_scene **out);
 /* The same for any mix of meshes, spheres and planes in Scene.objects order (RayTracer.getWhittedObjects /
@@ -239,6 +240,11 @@ int mi355rt_scene_epsilon(const mi355rt_scene *scene, float *epsilon_out);
  * and sizes of the flattened hierarchy. */
 int mi355rt_scene_object_info(const mi355rt_scene *scene, uint32_t object, float minmax[6], float *shadow_distance,
                               uint64_t *n_nodes, uint64_t *n_leaves, uint64_t *n_leaf_slots, int32_t *max_depth);
+/* Where scene creation spent its time, in seconds (the reference prints its own: TriangleMesh.java:84-85,123-124, KDTree.java:49-55):
+ * out[0] validation and bounds on the host (for a mesh the GPU builder does not take: its normals and hierarchy too); GPU builder:
+ * out[1] upload + vertex normals (TriangleMesh.computeNormals), out[2] hierarchy (KDNode), out[3] leaf groups, out[4] node records;
+ * out[5] host builder: records + leaf groups; out[6] copies into the scene's arrays. */
+int mi355rt_scene_build_seconds(const mi355rt_scene *scene, double out[7]);
 /* bytes of HBM held by the scene */
 int mi355rt_scene_device_bytes(const mi355rt_scene *scene, uint64_t *bytes_out);
 

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "mi355rt_scene_epsilon": (C.c_int, [C.c_void_p, c_float_p]),
     "mi355rt_scene_object_info": (C.c_int, [C.c_void_p, C.c_uint32, c_float_p, c_float_p, C.POINTER(C.c_uint64),
                                             C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), c_int32_p]),
+    "mi355rt_scene_build_seconds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "mi355rt_scene_device_bytes": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "mi355rt_camera_setup": (C.c_int, [C.c_void_p, c_float_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                        C.POINTER(CameraDesc)]),

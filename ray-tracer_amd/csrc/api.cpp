@@ -208,6 +208,9 @@ struct mi355rt_scene {
    size_t frame_pixels = 0;
    hipStream_t copy_stream = nullptr;   // mi355rt_render_host: device-to-host copies run beside each other
    int n_bouncing = 0;                  // objects with a ReflectionMaterial or RefractionMaterial
+   // seconds of scene creation: [0] validate + bounds (+ host normals and hierarchy), GPU builder: [1] upload + normals,
+   // [2] hierarchy, [3] leaf groups, [4] records; [5] host builder: records + leaf groups; [6] copies into the scene's arrays
+   double build_seconds[7] = { 0, 0, 0, 0, 0, 0, 0 };
    Multi *multi = nullptr;             // several GPUs behind this handle (mi355rt_scene_set_devices)
    // mi355rt_scene_view: a view shares the scene arrays of `parent` (everything a frame only reads) and owns what a frame
    // writes (scratch, counters, read-back block, statistics, timers, host-render frame buffers)
@@ -425,7 +428,14 @@ struct ScenePart {
    std::vector<DevNodeRec> nodes;    // links relative to the part: node index / index of a leaf's first descriptor
    std::vector<int32_t> slot_face;   // face id per leaf slot, the reference's order
    GroupedLeaves groups;             // descs (key / gbase relative to the part), group-face ids
-   bool on_gpu = false;              // built by gpu_build.hip
+   std::vector<float> fnrm;          // 12 floats per face: its three vertex normals
+   bool on_gpu = false;              // built by gpu_build.hip: everything above is empty, `gpu` holds the part's arrays on the device
+   GpuBuiltObject gpu;
+   size_t n_nodes = 0, n_slots = 0, n_descs = 0, n_gfaces = 0, face_base = 0, n_faces = 0;
+   ~ScenePart() { gpu_build_free(gpu); }
+   ScenePart() = default;
+   ScenePart(const ScenePart &) = delete;
+   ScenePart &operator=(const ScenePart &) = delete;
    size_t node_base = 0, slot_base = 0, desc_base = 0, gface_base = 0;
    int32_t root_link = 0, root_cnt = 0;
 };
@@ -459,11 +469,11 @@ void host_part_records(const BuiltObject &built, ScenePart &part)
 }
 
 // 48 bytes per face: the three vertex normals, fetched once per final hit
-void append_face_normals(std::vector<float> &all_fnrm, size_t face_base, const mi355rt_mesh_desc &md, const std::vector<float> &normals)
+void face_normals_of(std::vector<float> &fnrm, const mi355rt_mesh_desc &md, const std::vector<float> &normals)
 {
-   all_fnrm.resize(12 * (face_base + md.n_faces), 0.0f);
+   fnrm.assign(12 * (size_t) md.n_faces, 0.0f);
    for (size_t f = 0; f < md.n_faces; f++) {
-      float *dst = all_fnrm.data() + 12 * (face_base + f);
+      float *dst = fnrm.data() + 12 * f;
       for (int kx = 0; kx < 3; kx++) {
          const float *nrm = normals.data() + 3 * (size_t) md.indices[3 * f + kx];
          dst[4 * kx + 0] = nrm[0];
@@ -504,35 +514,45 @@ void finish_part(ScenePart &part, bool &boxes_finite)
 // Allocates the scene's node, descriptor, group-face and slot-id arrays and fills each part's share.  GFACE_PAD zero
 // faces follow the last group: a lane that sits a trip out reads entry 0, a leaf's last odd face reads one entry on.
 hipError_t upload_parts(mi355rt_scene *s, const std::vector<ScenePart> &parts, const mi355rt_object_desc *objects, size_t node_total, size_t slot_total,
-                        size_t desc_total, size_t gface_total)
+                        size_t desc_total, size_t gface_total, size_t face_total)
 {
    const size_t node_bytes = std::max<size_t>(node_total, 1) * sizeof(DevNodeRec);
    const size_t desc_bytes = (desc_total + DESC_PAD) * sizeof(LeafDesc);
    const size_t gface_floats = 12 * (gface_total + GFACE_PAD);
    const size_t slot_bytes = std::max<size_t>(slot_total, 1) * sizeof(int32_t);
+   const size_t fnrm_bytes = std::max<size_t>(12 * face_total * sizeof(float), 64);
    hipError_t e = hipMalloc(&s->d_nodes, node_bytes);
    if (e == hipSuccess) e = hipMalloc(&s->d_descs, desc_bytes);
    if (e == hipSuccess) e = hipMalloc(&s->d_gfaces, gface_floats * sizeof(float));
    if (e == hipSuccess) e = hipMalloc((void **) &s->d_slot_ids, slot_bytes);
+   if (e == hipSuccess) e = hipMalloc(&s->d_fnrm, fnrm_bytes);
    if (e != hipSuccess) return e;
-   s->device_bytes += node_bytes + desc_bytes + gface_floats * sizeof(float) + slot_bytes;
+   s->device_bytes += node_bytes + desc_bytes + gface_floats * sizeof(float) + slot_bytes + fnrm_bytes;
    s->n_node_recs = node_total;
    s->n_descs = desc_total;
    s->n_gface_floats = gface_floats;
    s->n_slots = slot_total;
+   s->n_fnrm_floats = 12 * face_total;
    e = hipMemset((float *) s->d_gfaces + 12 * gface_total, 0, 12 * (size_t) GFACE_PAD * sizeof(float));
    if (e == hipSuccess) e = hipMemset((LeafDesc *) s->d_descs + desc_total, 0, DESC_PAD * sizeof(LeafDesc));
    for (size_t i = 0; i < parts.size() && e == hipSuccess; i++) {
       const ScenePart &part = parts[i];
-      if (!part.nodes.empty())
-         e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, part.nodes.data(), part.nodes.size() * sizeof(DevNodeRec), hipMemcpyHostToDevice);
-      if (e == hipSuccess && !part.groups.descs.empty())
-         e = hipMemcpy((LeafDesc *) s->d_descs + part.desc_base, part.groups.descs.data(), part.groups.descs.size() * sizeof(LeafDesc), hipMemcpyHostToDevice);
-      if (e == hipSuccess && !part.slot_face.empty())
-         e = hipMemcpy(s->d_slot_ids + part.slot_base, part.slot_face.data(), part.slot_face.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-      if (e == hipSuccess && !part.groups.gface.empty())   // the faces' corners, gathered on the device
-         e = gpu_emit_gfaces(objects[i].mesh.vertices, objects[i].mesh.n_vertices, objects[i].mesh.indices, objects[i].mesh.n_faces,
-                             part.groups.gface.data(), part.groups.gface.size(), (float *) s->d_gfaces + 12 * part.gface_base);
+      const hipMemcpyKind kind = part.on_gpu ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;   // a part built on the GPU never left it
+      const void *nodes = part.on_gpu ? (const void *) part.gpu.nodes : part.nodes.data();
+      const void *descs = part.on_gpu ? (const void *) part.gpu.descs : part.groups.descs.data();
+      const void *slots = part.on_gpu ? (const void *) part.gpu.slot_ids : part.slot_face.data();
+      const void *fnrm = part.on_gpu ? (const void *) part.gpu.fnrm : part.fnrm.data();
+      if (part.n_nodes) e = hipMemcpy((DevNodeRec *) s->d_nodes + part.node_base, nodes, part.n_nodes * sizeof(DevNodeRec), kind);
+      if (e == hipSuccess && part.n_descs) e = hipMemcpy((LeafDesc *) s->d_descs + part.desc_base, descs, part.n_descs * sizeof(LeafDesc), kind);
+      if (e == hipSuccess && part.n_slots) e = hipMemcpy(s->d_slot_ids + part.slot_base, slots, part.n_slots * sizeof(int32_t), kind);
+      if (e == hipSuccess && part.n_faces) e = hipMemcpy((float *) s->d_fnrm + 12 * part.face_base, fnrm, 12 * part.n_faces * sizeof(float), kind);
+      if (e == hipSuccess && part.n_gfaces) {
+         if (part.on_gpu)
+            e = hipMemcpy((float *) s->d_gfaces + 12 * part.gface_base, part.gpu.gfaces, 12 * part.n_gfaces * sizeof(float), hipMemcpyDeviceToDevice);
+         else   // the faces' corners, gathered on the device
+            e = gpu_emit_gfaces(objects[i].mesh.vertices, objects[i].mesh.n_vertices, objects[i].mesh.indices, objects[i].mesh.n_faces,
+                                part.groups.gface.data(), part.groups.gface.size(), (float *) s->d_gfaces + 12 * part.gface_base);
+      }
    }
    if (e == hipSuccess) e = hipDeviceSynchronize();
    return e;
@@ -983,7 +1003,6 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
       // or on the GPU (gpu_build.hip), grouped on the host and copied to its place at the end
       std::vector<ScenePart> parts(n_meshes ? n_meshes : 1);
       bool boxes_finite = true;
-      std::vector<float> all_fnrm;
       size_t slot_total = 0, face_total = 0, node_total = 0, desc_total = 0, gface_total = 0;
       const Switches sw = switches();
       const bool allow_gpu_build = !sw.builder_host;   // MI355RT_BUILDER=host: never build on the GPU (tuning / tests); default: GPU where it applies
@@ -1018,85 +1037,108 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
                              md.vertices && md.indices;
             for (size_t v = 0; gpu_build && v < 3 * (size_t) md.n_vertices; v++) gpu_build = std::isfinite(md.vertices[v]);
             bo_obj.build_tree = !gpu_build;
+            bo_obj.synth_normals = !gpu_build;   // (a part built on the GPU gets its normals there too)
             BuiltObject bo_out;
             const auto t_prep = std::chrono::steady_clock::now();
             const std::string err = build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo_obj, bo_out);
             if (!err.empty()) {
-                              release_scene(s);
+               release_scene(s);
                return fail(err.find("max_depth") != std::string::npos ? MI355RT_E_LIMIT : MI355RT_E_ARG, "mesh " + std::to_string(i) + ": " + err);
             }
             const size_t face_base = face_total;
             uint64_t n_leaves = bo_out.n_leaves;
             int32_t tree_depth = bo_out.max_depth;
             const auto t_tree = std::chrono::steady_clock::now();
+            part.node_base = node_total;
+            part.slot_base = slot_total;
+            part.desc_base = desc_total;
+            part.gface_base = gface_total;
+            part.face_base = face_base;
+            part.n_faces = md.n_faces;
+            float part_max_normal = 0.0f;
             if (gpu_build) {
+               // normals, hierarchy, leaf groups and records all on the device, in their final form (absolute links): the
+               // part is copied into the scene's arrays device to device
                std::string gerr;
-               GpuBuiltObject built;
-               hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj, built, gerr);
-               if (ge == hipSuccess) {   // back to the host for the grouping pass
-                  part.nodes.resize((size_t) built.n_nodes);
-                  part.slot_face.resize((size_t) built.n_slots);
-                  ge = hipMemcpy(part.nodes.data(), built.nodes, sizeof(DevNodeRec) * part.nodes.size(), hipMemcpyDeviceToHost);
-                  if (ge == hipSuccess && built.n_slots)
-                     ge = hipMemcpy(part.slot_face.data(), built.slot_ids, sizeof(int32_t) * part.slot_face.size(), hipMemcpyDeviceToHost);
-               }
-               n_leaves = built.n_leaves;
-               tree_depth = built.max_depth;
-               gpu_build_free(built);
+               PartBases bases;
+               bases.node = node_total;
+               bases.slot = slot_total;
+               bases.desc = desc_total;
+               bases.gface = gface_total;
+               const hipError_t ge = gpu_build_object(md.vertices, md.n_vertices, md.normals, md.indices, md.n_faces, bo_out.bmin, bo_out.bmax, bo_obj,
+                                                      bases, part.gpu, gerr);
                if (ge != hipSuccess) {
                   release_scene(s);
                   if (!gerr.empty()) return fail(MI355RT_E_LIMIT, "mesh " + std::to_string(i) + ": " + gerr);
                   return hip_fail(ge, "GPU hierarchy build");
                }
+               n_leaves = part.gpu.n_leaves;
+               tree_depth = part.gpu.max_depth;
                part.on_gpu = true;
                s->any_gpu_build = true;
                part.root_link = 0;   // the GPU builder only takes meshes whose root splits: node 0
                part.root_cnt = 0;
+               part.n_nodes = (size_t) part.gpu.n_nodes;
+               part.n_slots = (size_t) part.gpu.n_slots;
+               part.n_descs = (size_t) part.gpu.n_descs;
+               part.n_gfaces = (size_t) part.gpu.n_gfaces;
+               s->n_groups += part.gpu.n_groups;
+               s->n_shared_groups += part.gpu.n_shared;
+               part_max_normal = part.gpu.max_normal_len;   // (every box of such a part is finite: its vertices are)
             } else {
                host_part_records(bo_out, part);
             }
-            part.node_base = node_total;
-            part.slot_base = slot_total;
-            part.desc_base = desc_total;
-            part.gface_base = gface_total;
             const bool root_is_leaf = !gpu_build && bo_out.root_is_leaf;
             const int32_t root_faces = part.root_cnt;
-            finish_part(part, boxes_finite);
-            if (node_total + part.nodes.size() > (size_t) 0x3ffffff0 || slot_total + part.slot_face.size() > (size_t) 0x3ffffff0 ||
-                face_base + md.n_faces > (size_t) 0x3ffffff0 || gface_total + part.groups.gface.size() > (size_t) 0x3ffffff0) {
+            if (!gpu_build) {
+               finish_part(part, boxes_finite);
+               part.n_nodes = part.nodes.size();
+               part.n_slots = part.slot_face.size();
+               part.n_descs = part.groups.descs.size();
+               part.n_gfaces = part.groups.gface.size();
+               s->n_groups += part.groups.n_groups;
+               s->n_shared_groups += part.groups.n_shared;
+               face_normals_of(part.fnrm, md, bo_out.normals);
+               for (size_t v = 0; v + 2 < bo_out.normals.size(); v += 3) {
+                  const float *nv = bo_out.normals.data() + v;
+                  const float len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+                  if (!(len <= part_max_normal)) part_max_normal = len;   // a NaN length sticks (and disables the any-hit shortcut)
+               }
+            }
+            if (node_total + part.n_nodes > (size_t) 0x3ffffff0 || slot_total + part.n_slots > (size_t) 0x3ffffff0 ||
+                face_base + md.n_faces > (size_t) 0x3ffffff0 || gface_total + part.n_gfaces > (size_t) 0x3ffffff0) {
                release_scene(s);
                return fail(MI355RT_E_LIMIT, "scene exceeds 2^30 nodes, leaf slots or faces");
             }
             const size_t node_base = node_total, slot_base = slot_total;
-            node_total += part.nodes.size();
-            slot_total += part.slot_face.size();
-            desc_total += part.groups.descs.size();
-            gface_total += part.groups.gface.size();
-            s->n_groups += part.groups.n_groups;
-            s->n_shared_groups += part.groups.n_shared;
-            if (sw.build_timing) {   // profiling aid
-               const auto t_end = std::chrono::steady_clock::now();
-               std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + normals + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
-                            gpu_build ? "" : " + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
-                            gpu_build ? "GPU hierarchy + download + leaf groups" : "records + leaf groups", std::chrono::duration<double>(t_end - t_tree).count());
+            node_total += part.n_nodes;
+            slot_total += part.n_slots;
+            desc_total += part.n_descs;
+            gface_total += part.n_gfaces;
+            const auto t_end = std::chrono::steady_clock::now();
+            s->build_seconds[0] += std::chrono::duration<double>(t_tree - t_prep).count();
+            if (gpu_build) {
+               for (int q = 0; q < 4; q++) s->build_seconds[1 + q] += part.gpu.seconds[q];
+            } else {
+               s->build_seconds[5] += std::chrono::duration<double>(t_end - t_tree).count();
             }
-            append_face_normals(all_fnrm, face_base, md, bo_out.normals);
+            if (sw.build_timing) {   // profiling aid
+               std::fprintf(stderr, "mi355rt build: object %u, %u faces: validate + bounds%s %.3f s, %s %.3f s\n", i, md.n_faces,
+                            gpu_build ? "" : " + normals + host hierarchy", std::chrono::duration<double>(t_tree - t_prep).count(),
+                            gpu_build ? "GPU normals + hierarchy + leaf groups + records" : "records + leaf groups", std::chrono::duration<double>(t_end - t_tree).count());
+            }
             face_total += md.n_faces;
 
             s->objects.emplace_back();
             s->materials.push_back(md.material);
-            for (size_t v = 0; v + 2 < bo_out.normals.size(); v += 3) {
-               const float *nv = bo_out.normals.data() + v;
-               const float len = std::sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-               if (!(len <= s->max_normal_len)) s->max_normal_len = len;   // a NaN length sticks (and disables the any-hit shortcut)
-            }
+            if (!(part_max_normal <= s->max_normal_len)) s->max_normal_len = part_max_normal;   // (a NaN sticks)
             HostObject &ho = s->objects.back();
             std::memcpy(ho.bmin, bo_out.bmin, sizeof(ho.bmin));
             std::memcpy(ho.bmax, bo_out.bmax, sizeof(ho.bmax));
             ho.shadow_distance = bo_out.shadow_distance;
-            ho.n_nodes = part.nodes.size();
+            ho.n_nodes = part.n_nodes;
             ho.n_leaves = n_leaves;
-            ho.n_slots = part.slot_face.size();
+            ho.n_slots = part.n_slots;
             ho.max_depth = tree_depth;
             ho.is_mesh = true;
             DevObject &d = dev_objs[i];
@@ -1122,16 +1164,14 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
          return fail(MI355RT_E_MEMORY, "out of host memory while building the hierarchy");
       }
       {
-         const hipError_t e = upload_parts(s, parts, objects, node_total, slot_total, desc_total, gface_total);
+         const auto t_up = std::chrono::steady_clock::now();
+         const hipError_t e = upload_parts(s, parts, objects, node_total, slot_total, desc_total, gface_total, face_total);
          if (e != hipSuccess) {
             release_scene(s);
             return hip_fail(e, "hierarchy upload");
          }
-         s->n_fnrm_floats = all_fnrm.size();
-         if (int rc = upload(all_fnrm.data(), all_fnrm.size() * sizeof(float), &s->d_fnrm, s)) {
-            release_scene(s);
-            return rc;
-         }
+         for (ScenePart &part : parts) gpu_build_free(part.gpu);   // (copied: the parts' own arrays go)
+         s->build_seconds[6] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_up).count();
       }
       float amax = 0.f;
       for (int c = 0; c < 3; c++) {
@@ -1262,6 +1302,16 @@ int mi355rt_debug_switch(const char *name, const char *value)
 {
    return guarded([&]() -> int {
       if (!set_switch(name, value)) return fail(MI355RT_E_ARG, std::string("unknown switch ") + (name ? name : ""));
+      return MI355RT_OK;
+   });
+}
+
+int mi355rt_scene_build_seconds(const mi355rt_scene *scene, double out[7])
+{
+   return guarded([&]() -> int {
+      if (!scene || !out) return fail(MI355RT_E_ARG, "null argument");
+      const mi355rt_scene *root = scene->parent ? scene->parent : scene;
+      for (int q = 0; q < 7; q++) out[q] = root->build_seconds[q];
       return MI355RT_OK;
    });
 }
@@ -1826,6 +1876,12 @@ int mi355rt_compute_normals(const float *vertices, uint32_t n_vertices, const in
       if ((n_vertices && !vertices) || (n_faces && !indices) || !normals_out) return fail(MI355RT_E_ARG, "null argument");
       for (size_t i = 0; i < 3 * (size_t) n_faces; i++) {
          if (indices[i] < 0 || (uint32_t) indices[i] >= n_vertices) return fail(MI355RT_E_ARG, "face index out of range");
+      }
+      // on the device (face-order sums per vertex: the host's bits) when there is one; the loader half of the library works without
+      int n_dev = 0;
+      if (n_faces > 50000 && hipGetDeviceCount(&n_dev) == hipSuccess && n_dev > 0) {
+         if (gpu_compute_normals(vertices, n_vertices, indices, n_faces, normals_out) == hipSuccess) return MI355RT_OK;
+         (void) hipGetLastError();
       }
       synthesise_normals(vertices, n_vertices, indices, n_faces, normals_out);
       return MI355RT_OK;

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 namespace mi355rt {
@@ -56,6 +57,7 @@ struct BNode {   // one node of the hierarchy under construction
    unsigned store;          // leaf: first entry in the leaf store
    unsigned n_int, n_slots, n_leaves;   // subtree totals: internal nodes, leaf slots, leaves
    unsigned dfs, sbase;     // internal: DFS pre-order number; any: first leaf slot of the subtree
+   unsigned parent;         // global node index, NONE for the root
 };
 
 // order-preserving map float -> unsigned (-0 < +0, as Java's Math.min / max order them)
@@ -180,6 +182,7 @@ __global__ void root_kernel(BNode *nodes, unsigned n_faces, float lx, float ly, 
    r.box[5] = float_key(hz);
    r.child[0] = r.child[1] = NONE;
    r.split = r.nl = r.nr = r.store = r.n_int = r.n_slots = r.n_leaves = r.dfs = r.sbase = 0;
+   r.parent = NONE;
    nodes[0] = r;
 }
 
@@ -233,8 +236,9 @@ __global__ void level_count_kernel(BNode *nodes, unsigned level_off, unsigned n_
    contrib[i] = c;
 }
 
-__device__ inline void init_child(BNode &ch, unsigned begin, unsigned count)
+__device__ inline void init_child(BNode &ch, unsigned begin, unsigned count, unsigned parent)
 {
+   ch.parent = parent;
    ch.begin = begin;
    ch.count = count;
    ch.box[0] = ch.box[1] = ch.box[2] = 0xffffffffu;   // min keys
@@ -255,11 +259,11 @@ __global__ void level_children_kernel(BNode *nodes, unsigned level_off, unsigned
    }
    unsigned ci = next_off + s.a;
    if (nd.nl) {
-      init_child(nodes[ci], s.b, nd.nl);
+      init_child(nodes[ci], s.b, nd.nl, level_off + i);
       nd.child[0] = ci++;
    }
    if (nd.nr) {
-      init_child(nodes[ci], s.b + nd.nl, nd.nr);
+      init_child(nodes[ci], s.b + nd.nl, nd.nr, level_off + i);
       nd.child[1] = ci;
    }
 }
@@ -385,7 +389,9 @@ __global__ void dfs_numbers_kernel(BNode *nodes, unsigned level_off, unsigned n_
    }
 }
 
-__global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, DevNodeRec *out)
+// node records in the uploaded form: links absolute (node_base / desc_base folded in); a leaf child's link is the index
+// of its first descriptor (slot_base[first slot].a, from the grouping pass below)
+__global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, const S2 *slot_base, unsigned node_base, unsigned desc_base, DevNodeRec *out)
 {
    const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= n_all) return;
@@ -401,7 +407,7 @@ __global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, DevNodeRec
             lo[c] = key_float(ch.box[c]);
             hi[c] = key_float(ch.box[3 + c]);
          }
-         link[s] = (int32_t) (ch.split ? ch.dfs : ch.sbase);
+         link[s] = (int32_t) (ch.split ? ch.dfs + node_base : slot_base[ch.sbase].a + desc_base);
          cnt[s] = ch.split ? 0 : (int32_t) ch.count;
       }
       r.lo_x[s] = lo[0];
@@ -415,18 +421,241 @@ __global__ void emit_nodes_kernel(const BNode *nodes, unsigned n_all, DevNodeRec
    r.rlink = link[1];
    r.lcnt = cnt[0];
    r.rcnt = cnt[1];
-   r.lgbase = r.rgbase = 0;   // filled in by the host's grouping pass (api.cpp finish_part)
+   r.lgbase = r.rgbase = 0;   // leaf_words_kernel, once the descriptors are complete
    r.lmask = r.rmask = 0u;
    out[nd.dfs] = r;
 }
 
-// leaf slots in the reference's order: the face id of every (leaf, face) pair
-__global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face, const unsigned *store_node, unsigned n_store, int32_t *slot_ids)
+// a leaf child's descriptor words ride in its parent's record (layout.h)
+__global__ void leaf_words_kernel(DevNodeRec *recs, unsigned n, const LeafDesc *descs, unsigned desc_base)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   DevNodeRec &r = recs[i];
+   if (r.llink != LINK_NONE && r.lcnt > 0) {
+      const LeafDesc d = descs[(unsigned) r.llink - desc_base];
+      r.lgbase = d.gbase;
+      r.lmask = d.mask;
+   }
+   if (r.rlink != LINK_NONE && r.rcnt > 0) {
+      const LeafDesc d = descs[(unsigned) r.rlink - desc_base];
+      r.rgbase = d.gbase;
+      r.rmask = d.mask;
+   }
+}
+
+// leaf slots in the reference's order: the face id of every (leaf, face) pair, and the first slot of the slot's leaf
+__global__ void emit_slots_kernel(const BNode *nodes, const unsigned *store_face, const unsigned *store_node, unsigned n_store, int32_t *slot_ids,
+                                  unsigned *slot_leaf)
 {
    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
    if (j >= n_store) return;
    const BNode &nd = nodes[store_node[j]];
    slot_ids[nd.sbase + (j - nd.store)] = (int32_t) store_face[j];
+   slot_leaf[nd.sbase + (j - nd.store)] = nd.sbase;
+}
+
+// ---------------------------------------------------------------- leaf groups (scene_build.hpp "leaf groups", Grouper)
+// The host's rule, top down: a subtree of at most GROUP_SLOTS leaf slots whose distinct faces number at most GROUP_FACES
+// is ONE group (its faces stored once, ascending; every leaf a mask over them); a leaf outside any such subtree is its
+// own group (faces in slot order, GROUP_FACES per descriptor).  Being such a subtree is inherited by every subtree of
+// it, so the groups are the qualifying nodes whose parent does not qualify.  Descriptors follow the leaves' DFS order
+// (= slot order) and group faces the groups' DFS order, so both places come from one scan over the slots.
+
+constexpr int GROUP_WAVES = 4;   // nodes per workgroup: one wave each
+
+// qual[g] = number of distinct faces of subtree g if it qualifies as a group, else 0
+__global__ __launch_bounds__(64 * GROUP_WAVES) void group_qualify_kernel(const BNode *nodes, unsigned n_all, const int32_t *slot_ids, unsigned *qual)
+{
+   __shared__ int32_t sh_ids[GROUP_WAVES][GROUP_SLOTS];
+   const unsigned g = blockIdx.x * GROUP_WAVES + (threadIdx.x >> 6);
+   const int lane = threadIdx.x & 63;
+   if (g >= n_all) return;
+   const BNode &nd = nodes[g];
+   if (!nd.split || nd.n_slots > (unsigned) GROUP_SLOTS) {
+      if (lane == 0) qual[g] = 0u;
+      return;
+   }
+   int32_t *ids = sh_ids[threadIdx.x >> 6];
+   const int n = (int) nd.n_slots;
+   for (int i = lane; i < n; i += 64) ids[i] = slot_ids[nd.sbase + (unsigned) i];
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_s_waitcnt(0xc07f);   // (one wave: its LDS writes are in order; wait for them before the reads)
+   unsigned distinct = 0;
+   for (int i = lane; i < n; i += 64) {
+      const int32_t v = ids[i];
+      bool first = true;
+      for (int j = 0; j < i; j++) first = first && ids[j] != v;
+      distinct += first ? 1u : 0u;
+   }
+   for (int off = 32; off > 0; off >>= 1) distinct += (unsigned) __shfl_xor((int) distinct, off, 64);
+   if (lane == 0) qual[g] = distinct <= (unsigned) GROUP_FACES ? distinct : 0u;
+}
+
+// per leaf: its descriptors; per group: its faces -- counted at the first slot of the leaf / group (cnt: .a descriptors, .b group faces)
+__global__ void group_count_kernel(const BNode *nodes, unsigned n_all, const unsigned *qual, S2 *cnt, unsigned long long *totals)
+{
+   const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= n_all) return;
+   const BNode &nd = nodes[g];
+   const bool parent_ok = nd.parent != NONE && qual[nd.parent] != 0u;
+   if (nd.split) {
+      if (qual[g] != 0u && !parent_ok) {   // a group of several leaves
+         cnt[nd.sbase].b = qual[g];
+         atomicAdd(totals + 0, 1ull);
+         atomicAdd(totals + 1, 1ull);
+      }
+   } else if (parent_ok) {
+      cnt[nd.sbase].a = 1u;
+   } else {   // a leaf on its own
+      const unsigned chunks = (nd.count + GROUP_FACES - 1) / GROUP_FACES;
+      cnt[nd.sbase].a = chunks;
+      cnt[nd.sbase].b = nd.count;
+      atomicAdd(totals + 0, (unsigned long long) chunks);
+   }
+}
+
+// one wave per group of several leaves: its distinct faces ascending, then every leaf's mask over them
+__global__ __launch_bounds__(64 * GROUP_WAVES) void group_emit_kernel(const BNode *nodes, unsigned n_all, const unsigned *qual, const int32_t *slot_ids,
+                                                                     const unsigned *slot_leaf, const S2 *base, PartBases bases, LeafDesc *descs,
+                                                                     int32_t *gface_ids)
+{
+   __shared__ int32_t sh_ids[GROUP_WAVES][GROUP_SLOTS];
+   __shared__ unsigned char sh_first[GROUP_WAVES][GROUP_SLOTS];
+   const unsigned g = blockIdx.x * GROUP_WAVES + (threadIdx.x >> 6);
+   const int lane = threadIdx.x & 63;
+   if (g >= n_all) return;
+   const BNode &nd = nodes[g];
+   if (!nd.split || qual[g] == 0u || (nd.parent != NONE && qual[nd.parent] != 0u)) return;
+   int32_t *ids = sh_ids[threadIdx.x >> 6];
+   unsigned char *first = sh_first[threadIdx.x >> 6];
+   const int n = (int) nd.n_slots;
+   for (int i = lane; i < n; i += 64) ids[i] = slot_ids[nd.sbase + (unsigned) i];
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   for (int i = lane; i < n; i += 64) {
+      const int32_t v = ids[i];
+      bool f = true;
+      for (int j = 0; j < i; j++) f = f && ids[j] != v;
+      first[i] = f ? 1 : 0;
+   }
+   __builtin_amdgcn_wave_barrier();
+   __builtin_amdgcn_s_waitcnt(0xc07f);
+   const unsigned gbase = base[nd.sbase].b;   // the group's first entry among the object's group faces
+   for (int i = lane; i < n; i += 64) {
+      const int32_t v = ids[i];
+      unsigned pos = 0;   // rank of v among the distinct faces
+      for (int j = 0; j < n; j++) pos += (first[j] && ids[j] < v) ? 1u : 0u;
+      if (first[i]) gface_ids[gbase + pos] = v;
+      const unsigned leaf = slot_leaf[nd.sbase + (unsigned) i];
+      LeafDesc *d = descs + base[leaf].a;
+      atomicOr(&d->mask, 1u << pos);
+      if (nd.sbase + (unsigned) i == leaf) {
+         d->key = (int32_t) (leaf + (unsigned) bases.slot);
+         d->gbase = (int32_t) (gbase + (unsigned) bases.gface);
+      }
+   }
+}
+
+// leaves on their own: GROUP_FACES faces per descriptor, in slot order
+__global__ void group_alone_kernel(const BNode *nodes, unsigned n_all, const unsigned *qual, const int32_t *slot_ids, const S2 *base, PartBases bases,
+                                   LeafDesc *descs, int32_t *gface_ids)
+{
+   const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= n_all) return;
+   const BNode &nd = nodes[g];
+   if (nd.split || (nd.parent != NONE && qual[nd.parent] != 0u)) return;
+   const unsigned d0 = base[nd.sbase].a, g0 = base[nd.sbase].b, cnt = nd.count;
+   for (unsigned done = 0, c = 0; done < cnt; done += GROUP_FACES, c++) {
+      const unsigned n = min((unsigned) GROUP_FACES, cnt - done);
+      LeafDesc d;
+      d.key = (int32_t) (nd.sbase + (unsigned) bases.slot);
+      d.gbase = ((int32_t) (g0 + done + (unsigned) bases.gface)) | DESC_IDENT | (done + n < cnt ? DESC_MORE : 0);
+      d.mask = n == 32u ? 0xffffffffu : ((1u << n) - 1u);
+      d.pad = 0;
+      descs[d0 + c] = d;
+   }
+   for (unsigned k = 0; k < cnt; k++) gface_ids[g0 + k] = slot_ids[nd.sbase + k];
+}
+
+// ---------------------------------------------------------------- vertex normals (TriangleMesh.computeNormals, sceneObjects/TriangleMesh.java:96-126)
+// The reference adds every face's unit normal to its three vertices in FACE ORDER and divides each sum by its length;
+// f32 sums depend on their order, so each vertex gets the list of its faces, sorted, and adds them up in that order.
+
+__global__ void normal_count_kernel(const int32_t *indices, unsigned n_faces, unsigned *count)
+{
+   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;   // one (face, corner)
+   if (c >= 3u * n_faces) return;
+   atomicAdd(count + indices[c], 1u);
+}
+__global__ void normal_fill_kernel(const int32_t *indices, unsigned n_faces, const unsigned *offset, unsigned *cursor, unsigned *inc)
+{
+   const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+   if (c >= 3u * n_faces) return;
+   const int32_t v = indices[c];
+   inc[offset[v] + atomicAdd(cursor + v, 1u)] = c / 3u;
+}
+// RTStatics.computeNormal (RTStatics.java:323-336) with Vector3f.normalize
+__device__ inline void face_normal(const float *vertices, const int32_t *indices, unsigned f, float n[3])
+{
+   const int32_t *face = indices + 3 * (size_t) f;
+   const float *a = vertices + 3 * (size_t) face[0], *b = vertices + 3 * (size_t) face[1], *c = vertices + 3 * (size_t) face[2];
+   const float e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { c[0] - a[0], c[1] - a[1], c[2] - a[2] };
+   const float x = e1[1] * e2[2] - e1[2] * e2[1], y = e2[0] * e1[2] - e2[2] * e1[0], z = e1[0] * e2[1] - e1[1] * e2[0];
+   const float len2 = x * x + y * y + z * z;
+   const float inv = (float) (1.0 / sqrt((double) len2));
+   n[0] = x * inv;
+   n[1] = y * inv;
+   n[2] = z * inv;
+}
+__global__ void normal_sum_kernel(const float *vertices, const int32_t *indices, unsigned n_vertices, const unsigned *offset, unsigned *inc, float *normals)
+{
+   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+   if (v >= n_vertices) return;
+   const unsigned b = offset[v], e = offset[v + 1];
+   for (unsigned i = b + 1; i < e; i++) {   // the vertex's faces ascending (a handful; equal ids -- a face with this corner twice -- stay twice)
+      const unsigned f = inc[i];
+      unsigned j = i;
+      for (; j > b && inc[j - 1] > f; j--) inc[j] = inc[j - 1];
+      inc[j] = f;
+   }
+   float d[3] = { 0.0f, 0.0f, 0.0f };
+   for (unsigned i = b; i < e; i++) {
+      float n[3];
+      face_normal(vertices, indices, inc[i], n);
+      d[0] += n[0];
+      d[1] += n[1];
+      d[2] += n[2];
+   }
+   const float sq = (0.0f - d[0]) * (0.0f - d[0]) + (0.0f - d[1]) * (0.0f - d[1]) + (0.0f - d[2]) * (0.0f - d[2]);   // RTStatics.getDistance from the origin
+   const float len = (float) sqrt((double) sq);
+   d[0] /= len;
+   d[1] /= len;
+   d[2] /= len;
+   normals[3 * (size_t) v + 0] = d[0];
+   normals[3 * (size_t) v + 1] = d[1];
+   normals[3 * (size_t) v + 2] = d[2];
+}
+// the longest normal (bounds the shadow rays' origin offset, api.cpp); a NaN length sticks
+__global__ void normal_max_kernel(const float *normals, unsigned n_vertices, unsigned *max_len_bits, unsigned *any_nan)
+{
+   const unsigned v = blockIdx.x * blockDim.x + threadIdx.x;
+   if (v >= n_vertices) return;
+   const float *nv = normals + 3 * (size_t) v;
+   const float len = sqrtf(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+   if (len != len) atomicOr(any_nan, 1u);
+   else atomicMax(max_len_bits, __float_as_uint(len));   // non-negative floats order as their bits
+}
+// 48 bytes per face: its three vertex normals (fetched once per final hit)
+__global__ void face_normals_kernel(const float *normals, const int32_t *indices, unsigned n_faces, float *fnrm)
+{
+   const unsigned f = blockIdx.x * blockDim.x + threadIdx.x;
+   if (f >= n_faces) return;
+   float4 *dst = (float4 *) fnrm + 3 * (size_t) f;
+   for (int k = 0; k < 3; k++) {
+      const float *nv = normals + 3 * (size_t) indices[3 * (size_t) f + k];
+      dst[k] = make_float4(nv[0], nv[1], nv[2], 0.0f);
+   }
 }
 
 // group faces (layout.h): { v0.xyz, faceId } { v1.xyz, 0 } { v2.xyz, 0 } for every entry of the group-face list
@@ -451,9 +680,15 @@ unsigned grid_for(size_t n) { return (unsigned) ((n + 255) / 256); }
 template <typename T> struct DevVec {
    T *p = nullptr;
    size_t cap = 0;
-   ~DevVec()
+   DevVec() = default;
+   DevVec(const DevVec &) = delete;
+   DevVec &operator=(const DevVec &) = delete;
+   ~DevVec() { release(); }
+   void release()
    {
       if (p) (void) hipFree(p);
+      p = nullptr;
+      cap = 0;
    }
    hipError_t ensure(size_t n, size_t keep)
    {
@@ -491,20 +726,87 @@ template <typename T> hipError_t exclusive_scan(const T *in, size_t n, T *out, D
 
 void gpu_build_free(GpuBuiltObject &o)
 {
-   if (o.nodes) (void) hipFree(o.nodes);
-   if (o.slot_ids) (void) hipFree(o.slot_ids);
+   void *all[] = { o.nodes, o.slot_ids, o.descs, o.gfaces, o.fnrm };
+   for (void *q : all)
+      if (q) (void) hipFree(q);
    o = GpuBuiltObject();
 }
 
-hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, const float bmin[3],
-                            const float bmax[3], const BuildOptions &opts, GpuBuiltObject &out, std::string &err)
+namespace {
+
+// one unsigned per item -> exclusive scan, through the S2 scan (its .b lane idles)
+struct U1Scan {
+   DevVec<S2> in, out, bsum;
+};
+
+__global__ void widen_kernel(const unsigned *in, unsigned n, S2 *out)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) out[i] = S2 { in[i], 0u };
+}
+__global__ void narrow_kernel(const S2 *in, unsigned n, unsigned *out)
+{
+   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) out[i] = in[i].a;
+}
+
+// TriangleMesh.computeNormals on device arrays; d_normals: n_vertices * 3
+hipError_t device_normals(const float *d_vertices, const int32_t *d_indices, uint32_t n_vertices, uint32_t n_faces, float *d_normals)
+{
+   DevVec<unsigned> count, offset, inc;
+   U1Scan sc;
+   GB_TRY(count.ensure((size_t) n_vertices + 1, 0));
+   GB_TRY(offset.ensure((size_t) n_vertices + 1, 0));
+   GB_TRY(inc.ensure(std::max<size_t>(3 * (size_t) n_faces, 1), 0));
+   GB_TRY(sc.in.ensure((size_t) n_vertices + 1, 0));
+   GB_TRY(sc.out.ensure((size_t) n_vertices + 2, 0));
+   GB_TRY(hipMemsetAsync(count.p, 0, sizeof(unsigned) * ((size_t) n_vertices + 1), nullptr));
+   if (n_faces) hipLaunchKernelGGL(normal_count_kernel, dim3(grid_for(3 * (size_t) n_faces)), dim3(256), 0, nullptr, d_indices, n_faces, count.p);
+   hipLaunchKernelGGL(widen_kernel, dim3(grid_for(n_vertices)), dim3(256), 0, nullptr, count.p, n_vertices, sc.in.p);
+   GB_TRY(exclusive_scan<S2>(sc.in.p, n_vertices, sc.out.p, sc.bsum));
+   hipLaunchKernelGGL(narrow_kernel, dim3(grid_for((size_t) n_vertices + 1)), dim3(256), 0, nullptr, sc.out.p, n_vertices + 1, offset.p);
+   GB_TRY(hipMemsetAsync(count.p, 0, sizeof(unsigned) * ((size_t) n_vertices + 1), nullptr));   // now the fill cursors
+   if (n_faces) hipLaunchKernelGGL(normal_fill_kernel, dim3(grid_for(3 * (size_t) n_faces)), dim3(256), 0, nullptr, d_indices, n_faces, offset.p, count.p, inc.p);
+   if (n_vertices) hipLaunchKernelGGL(normal_sum_kernel, dim3(grid_for(n_vertices)), dim3(256), 0, nullptr, d_vertices, d_indices, n_vertices, offset.p, inc.p, d_normals);
+   GB_TRY(hipGetLastError());
+   return hipDeviceSynchronize();   // the temporaries go out of scope
+}
+
+double seconds_since(std::chrono::steady_clock::time_point &t)
+{
+   const auto now = std::chrono::steady_clock::now();
+   const double s = std::chrono::duration<double>(now - t).count();
+   t = now;
+   return s;
+}
+
+}   // namespace
+
+hipError_t gpu_compute_normals(const float *vertices, uint32_t n_vertices, const int32_t *indices, uint32_t n_faces, float *normals_out)
+{
+   DevVec<float> d_vertices, d_normals;
+   DevVec<int32_t> d_indices;
+   GB_TRY(d_vertices.ensure(std::max<size_t>(3 * (size_t) n_vertices, 1), 0));
+   GB_TRY(d_normals.ensure(std::max<size_t>(3 * (size_t) n_vertices, 1), 0));
+   GB_TRY(d_indices.ensure(std::max<size_t>(3 * (size_t) n_faces, 1), 0));
+   if (n_vertices) GB_TRY(hipMemcpy(d_vertices.p, vertices, sizeof(float) * 3 * (size_t) n_vertices, hipMemcpyHostToDevice));
+   if (n_faces) GB_TRY(hipMemcpy(d_indices.p, indices, sizeof(int32_t) * 3 * (size_t) n_faces, hipMemcpyHostToDevice));
+   GB_TRY(device_normals(d_vertices.p, d_indices.p, n_vertices, n_faces, d_normals.p));
+   if (n_vertices) GB_TRY(hipMemcpy(normals_out, d_normals.p, sizeof(float) * 3 * (size_t) n_vertices, hipMemcpyDeviceToHost));
+   return hipSuccess;
+}
+
+hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const float *normals, const int32_t *indices, uint32_t n_faces,
+                            const float bmin[3], const float bmax[3], const BuildOptions &opts, const PartBases &bases, GpuBuiltObject &out,
+                            std::string &err)
 {
    out = GpuBuiltObject();
    if (!opts.use_kdtree || n_faces <= (uint32_t) opts.max_children || opts.max_depth < 1 || n_faces > 0x3fffffffu) {
       err = "gpu_build_object: the root must split";
       return hipErrorInvalidValue;
    }
-   DevVec<float> d_vertices, d_fb;
+   auto t_mark = std::chrono::steady_clock::now();
+   DevVec<float> d_vertices, d_fb, d_normals;
    DevVec<int32_t> d_indices;
    DevVec<unsigned> ent_face[2], ent_node[2], store_face, store_node;
    DevVec<BNode> nodes;
@@ -515,6 +817,28 @@ hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const in
    GB_TRY(d_fb.ensure(6 * (size_t) n_faces, 0));
    GB_TRY(hipMemcpy(d_vertices.p, vertices, sizeof(float) * 3 * (size_t) n_vertices, hipMemcpyHostToDevice));
    GB_TRY(hipMemcpy(d_indices.p, indices, sizeof(int32_t) * 3 * (size_t) n_faces, hipMemcpyHostToDevice));
+   {   // the vertex normals: the mesh's own, or TriangleMesh.computeNormals; then the longest, and three per face
+      GB_TRY(d_normals.ensure(3 * (size_t) n_vertices, 0));
+      if (normals) GB_TRY(hipMemcpy(d_normals.p, normals, sizeof(float) * 3 * (size_t) n_vertices, hipMemcpyHostToDevice));
+      else GB_TRY(device_normals(d_vertices.p, d_indices.p, n_vertices, n_faces, d_normals.p));
+      DevVec<unsigned> red;
+      GB_TRY(red.ensure(2, 0));
+      GB_TRY(hipMemsetAsync(red.p, 0, 2 * sizeof(unsigned), nullptr));
+      hipLaunchKernelGGL(normal_max_kernel, dim3(grid_for(n_vertices)), dim3(256), 0, nullptr, d_normals.p, n_vertices, red.p, red.p + 1);
+      unsigned r[2] = { 0u, 0u };
+      GB_TRY(hipMemcpy(r, red.p, sizeof(r), hipMemcpyDeviceToHost));
+      union {
+         unsigned u;
+         float f;
+      } c;
+      c.u = r[0];
+      out.max_normal_len = r[1] ? __builtin_nanf("") : c.f;
+      GB_TRY(hipMalloc((void **) &out.fnrm, sizeof(float) * 12 * (size_t) n_faces));
+      hipLaunchKernelGGL(face_normals_kernel, dim3(grid_for(n_faces)), dim3(256), 0, nullptr, d_normals.p, d_indices.p, n_faces, out.fnrm);
+      GB_TRY(hipGetLastError());
+   }
+   GB_TRY(hipDeviceSynchronize());
+   out.seconds[0] = seconds_since(t_mark);
    GB_TRY(ent_face[0].ensure(n_faces, 0));
    GB_TRY(ent_node[0].ensure(n_faces, 0));
    GB_TRY(nodes.ensure(1024, 0));
@@ -543,6 +867,7 @@ hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const in
       GB_TRY(hipMemcpy(&tot, scan_n.p + n_level, sizeof(S4), hipMemcpyDeviceToHost));   // children, next entries, leaf entries, splits
       if ((size_t) tot.b > 0x7ffffff0u || store_used + tot.c > 0x7ffffff0u || n_all + tot.a > 0x7ffffff0u) {
          err = "hierarchy too large: leaf slots exceed 32-bit addressing";
+         gpu_build_free(out);
          return hipErrorInvalidValue;
       }
       const int nxt = cur ^ 1;
@@ -574,23 +899,86 @@ hipError_t gpu_build_object(const float *vertices, uint32_t n_vertices, const in
    GB_TRY(hipMemcpy(&root, nodes.p, sizeof(BNode), hipMemcpyDeviceToHost));
    if (root.n_slots != store_used || !root.split) {
       err = "gpu_build_object: internal inconsistency (leaf store does not match the hierarchy)";
+      gpu_build_free(out);
       return hipErrorUnknown;
    }
+   out.seconds[1] = seconds_since(t_mark);
    out.n_nodes = root.n_int;
    out.n_slots = root.n_slots;
    out.n_leaves = root.n_leaves;
    out.max_depth = (int32_t) level_off.size() - 1;
-   GB_TRY(hipMalloc((void **) &out.nodes, sizeof(DevNodeRec) * (size_t) out.n_nodes));
-   hipError_t e = hipMalloc((void **) &out.slot_ids, sizeof(int32_t) * (size_t) std::max<uint64_t>(out.n_slots, 1));
+   // the temporaries of the levels are not needed any more: the grouping pass wants the room (a 28-million-face mesh: GBs)
+   for (int k = 0; k < 2; k++) {
+      ent_face[k].release();
+      ent_node[k].release();
+   }
+   flags.release();
+   scan_e.release();
+   d_fb.release();
+
+   // ---- leaf slots, then the leaf groups (descriptors and group faces), then the records
+   const size_t n_slots = store_used;
+   DevVec<unsigned> slot_leaf, qual;
+   DevVec<S2> cnt, base, bsum_g;
+   DevVec<unsigned long long> totals;
+   DevVec<int32_t> gface_ids;
+   hipError_t e = hipMalloc((void **) &out.slot_ids, sizeof(int32_t) * std::max<size_t>(n_slots, 1));
+   if (e == hipSuccess) e = slot_leaf.ensure(std::max<size_t>(n_slots, 1), 0);
+   if (e == hipSuccess) e = qual.ensure(n_all, 0);
+   if (e == hipSuccess) e = cnt.ensure(n_slots + 1, 0);
+   if (e == hipSuccess) e = base.ensure(n_slots + 2, 0);
+   if (e == hipSuccess) e = totals.ensure(2, 0);
+   if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(S2) * (n_slots + 1), nullptr);
+   if (e == hipSuccess) e = hipMemsetAsync(totals.p, 0, 2 * sizeof(unsigned long long), nullptr);
    if (e != hipSuccess) {
       gpu_build_free(out);
       return e;
    }
-   hipLaunchKernelGGL(emit_nodes_kernel, dim3(grid_for(n_all)), dim3(256), 0, nullptr, nodes.p, (unsigned) n_all, out.nodes);
    hipLaunchKernelGGL(emit_slots_kernel, dim3(grid_for(store_used)), dim3(256), 0, nullptr, nodes.p, store_face.p, store_node.p, (unsigned) store_used,
-                      out.slot_ids);
+                      out.slot_ids, slot_leaf.p);
+   const unsigned group_grid = (unsigned) ((n_all + GROUP_WAVES - 1) / GROUP_WAVES);
+   hipLaunchKernelGGL(group_qualify_kernel, dim3(group_grid), dim3(64 * GROUP_WAVES), 0, nullptr, nodes.p, (unsigned) n_all, out.slot_ids, qual.p);
+   hipLaunchKernelGGL(group_count_kernel, dim3(grid_for(n_all)), dim3(256), 0, nullptr, nodes.p, (unsigned) n_all, qual.p, cnt.p, totals.p);
+   e = hipGetLastError();
+   if (e == hipSuccess) e = exclusive_scan<S2>(cnt.p, n_slots, base.p, bsum_g);
+   S2 tot_g { 0u, 0u };
+   unsigned long long tot_groups[2] = { 0ull, 0ull };
+   if (e == hipSuccess) e = hipMemcpy(&tot_g, base.p + n_slots, sizeof(S2), hipMemcpyDeviceToHost);
+   if (e == hipSuccess) e = hipMemcpy(tot_groups, totals.p, sizeof(tot_groups), hipMemcpyDeviceToHost);
+   if (e == hipSuccess) {
+      out.n_descs = tot_g.a;
+      out.n_gfaces = tot_g.b;
+      out.n_groups = tot_groups[0];
+      out.n_shared = tot_groups[1];
+      e = hipMalloc((void **) &out.descs, sizeof(LeafDesc) * std::max<size_t>(out.n_descs, 1));
+   }
+   if (e == hipSuccess) e = hipMemsetAsync(out.descs, 0, sizeof(LeafDesc) * std::max<size_t>(out.n_descs, 1), nullptr);
+   if (e == hipSuccess) e = gface_ids.ensure(std::max<size_t>(out.n_gfaces, 1), 0);
+   if (e == hipSuccess) e = hipMalloc((void **) &out.gfaces, sizeof(float) * 12 * std::max<size_t>(out.n_gfaces, 1));
+   if (e == hipSuccess) e = hipMalloc((void **) &out.nodes, sizeof(DevNodeRec) * (size_t) out.n_nodes);
+   if (e != hipSuccess) {
+      gpu_build_free(out);
+      return e;
+   }
+   hipLaunchKernelGGL(group_emit_kernel, dim3(group_grid), dim3(64 * GROUP_WAVES), 0, nullptr, nodes.p, (unsigned) n_all, qual.p, out.slot_ids, slot_leaf.p,
+                      base.p, bases, out.descs, gface_ids.p);
+   hipLaunchKernelGGL(group_alone_kernel, dim3(grid_for(n_all)), dim3(256), 0, nullptr, nodes.p, (unsigned) n_all, qual.p, out.slot_ids, base.p, bases,
+                      out.descs, gface_ids.p);
+   if (out.n_gfaces)
+      hipLaunchKernelGGL(emit_gfaces_kernel, dim3(grid_for(out.n_gfaces)), dim3(256), 0, nullptr, d_vertices.p, d_indices.p, gface_ids.p, (size_t) out.n_gfaces,
+                         out.gfaces);
    e = hipGetLastError();
    if (e == hipSuccess) e = hipDeviceSynchronize();
+   out.seconds[2] = seconds_since(t_mark);
+   if (e == hipSuccess) {
+      hipLaunchKernelGGL(emit_nodes_kernel, dim3(grid_for(n_all)), dim3(256), 0, nullptr, nodes.p, (unsigned) n_all, base.p, (unsigned) bases.node,
+                         (unsigned) bases.desc, out.nodes);
+      hipLaunchKernelGGL(leaf_words_kernel, dim3(grid_for(out.n_nodes)), dim3(256), 0, nullptr, out.nodes, (unsigned) out.n_nodes, out.descs,
+                         (unsigned) bases.desc);
+      e = hipGetLastError();
+   }
+   if (e == hipSuccess) e = hipDeviceSynchronize();
+   out.seconds[3] = seconds_since(t_mark);
    if (e != hipSuccess) gpu_build_free(out);
    return e;
 }

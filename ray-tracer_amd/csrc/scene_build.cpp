@@ -393,7 +393,8 @@ std::string build_object(const float *vertices, uint32_t n_vertices, const float
    out = BuiltObject();
    out.normals.resize(3 * (size_t) n_vertices);
    if (normals) std::copy(normals, normals + 3 * (size_t) n_vertices, out.normals.begin());
-   else synthesise_normals(vertices, n_vertices, indices, n_faces, out.normals.data());
+   else if (opts.synth_normals) synthesise_normals(vertices, n_vertices, indices, n_faces, out.normals.data());
+   else out.normals.clear();
 
    for (int c = 0; c < 3; c++) {
       out.bmin[c] = jm::kFloatMax;

@@ -13,6 +13,7 @@ struct BuildOptions {
    int max_children = 5;
    bool use_kdtree = true;
    bool build_tree = true;   // false: validate, normals and bounds only (the hierarchy comes from gpu_build.hip)
+   bool synth_normals = true;   // false: a mesh without normals keeps none (gpu_build.hip makes them on the device)
 };
 
 struct BuiltObject {

@@ -393,6 +393,13 @@ class Scene:
         _abi.check(self._lib.mi355rt_debug_scene_digest(self._handle, out))
         return (out[0], out[1], out[2]), bool(out[3])
 
+    def build_seconds(self):
+        """mi355rt_scene_build_seconds: where scene creation spent its time."""
+        out = (C.c_double * 7)()
+        _abi.check(self._lib.mi355rt_scene_build_seconds(self._handle, out))
+        return dict(zip(("host_validate_bounds", "gpu_upload_normals", "gpu_hierarchy", "gpu_leaf_groups", "gpu_records", "host_records_groups",
+                         "copy_to_scene"), [round(float(x), 4) for x in out]))
+
     def device_bytes(self):
         b = C.c_uint64()
         _abi.check(self._lib.mi355rt_scene_device_bytes(self._handle, C.byref(b)))

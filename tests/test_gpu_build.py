@@ -77,3 +77,26 @@ def test_dragon_class_full_size(rt):
     v, i = rt.meshgen.stanford_standin("dragon")
     info = _same(rt, [(v, i)])
     assert info["n_leaf_slots"] == 6023242 and info["n_nodes"] == 798804 and info["max_depth"] == 20
+
+
+def test_thai_class_ten_million_faces(rt):
+    """BASELINE configs[3]'s mesh size: 10,000,000 faces (leaves of tens of faces under the reference's depth limit) -- the
+    device's hierarchy, leaf groups, records and normals against the host builder's, byte for byte."""
+    v, i = rt.meshgen.blob(10000000, span=400.0, stretch=(0.59, 1.0, 0.52), seed=4)
+    info = _same(rt, [(v, i)])
+    assert info["max_depth"] == 20 and info["n_leaf_slots"] > 10000000
+
+
+def test_normals_on_the_device_are_the_oracles(rt, orc):
+    """TriangleMesh.computeNormals on the device (face-order sums per vertex) against the oracle's loop, bit for bit:
+    a blob, with repeated faces, faces with two equal corners (NaN normals that spread, TriangleMesh.java:96-126),
+    an unreferenced vertex (0 / 0) and a vertex of very high valence."""
+    v, i = rt.meshgen.blob(300000, span=0.3, seed=21)
+    fan = np.stack([np.zeros(3000, dtype=np.int32), np.arange(1, 3001, dtype=np.int32), np.arange(2, 3002, dtype=np.int32)], axis=1)   # vertex 0: +3000 faces
+    i = np.ascontiguousarray(np.concatenate([i, i[:500], fan, np.int32([[7, 7, 9], [11, 12, 12]])]))
+    v = np.ascontiguousarray(np.concatenate([v, np.float32([[9, 9, 9]])]))
+    got = rt.compute_normals(v, i)                      # more than 50,000 faces: the device path
+    exp = np.empty_like(v)
+    orc.lib().orc_compute_normals(orc.P(v), v.shape[0], orc.PI(i), i.shape[0], orc.P(exp))
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+    assert np.isnan(got[-1]).all() and np.isnan(got[7]).all() and np.isfinite(got[100]).all()
