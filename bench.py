@@ -259,11 +259,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dry_run_gloo:
         sys.exit(dry_run_gloo(args, rank, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
     if lib_ranks > 1 and not args.rehearse_one_gpu and torch.cuda.device_count() < lib_ranks:
         raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report a %d-GPU number from fewer GPUs"
                          % (lib_ranks, torch.cuda.device_count(), lib_ranks))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rehearse = args.rehearse_one_gpu and world > 1

@@ -295,6 +295,24 @@ class Scene {
    ~Scene() { mi355rt_scene_destroy(handle_); }
    mi355rt_scene *handle() const { return handle_; }
 
+   // mi355rt_scene_set_devices: every later frame of this scene (and of its views) is spread over these GPUs inside the one
+   // render call, as Camera.createImage spreads pixels over availableProcessors() threads (Camera.java:129-182).
+   // devices[0] must be the device the scene was created on; naming a device twice is allowed (two ranks on it).
+   void setDevices(const std::vector<int32_t> &devices) { check(mi355rt_scene_set_devices(handle_, devices.data(), (uint32_t) devices.size())); }
+   mi355rt_multi_info multiInfo() const
+   {
+      mi355rt_multi_info info {};
+      check(mi355rt_scene_multi_info(handle_, &info));
+      return info;
+   }
+   // seconds of the phases of scene creation (what TriangleMesh.java:84-85 and KDTree.java:49-55 print)
+   std::array<double, 7> buildSeconds() const
+   {
+      std::array<double, 7> t {};
+      check(mi355rt_scene_build_seconds(handle_, t.data()));
+      return t;
+   }
+
  private:
    mi355rt_scene *handle_ = nullptr;
 };
@@ -325,6 +343,7 @@ class Camera {
    std::vector<int32_t> hitId;
    std::vector<int32_t> hitObj;   // index into Scene.objects, -1 = miss
    std::vector<float> hitW;
+   std::vector<uint32_t> image;   // Camera.image (Camera.java:103-107): 0xFFrrggbb, row-major
 
    Camera(const Scene &s, int ms, int brdf, float nearPlane, int width, int height)
       : scene(s), multiSamples(ms), brdfSamples(brdf), screenWidth(width), screenHeight(height), nearPlaneDistance(nearPlane)
@@ -362,8 +381,15 @@ class Camera {
       hitId.assign(n, -1);
       hitObj.assign(n, -1);
       hitW.assign(n, 0.0f);
+      image.assign(n, 0u);
       const mi355rt_settings st = settings();
-      check(mi355rt_render(scene.handle(), &cam, &st, rows_.data(), hitId.data(), hitObj.data(), hitW.data()));
+      mi355rt_host_frame out {};
+      out.rgb = rows_.data();
+      out.argb8 = image.data();
+      out.hit_id = hitId.data();
+      out.hit_obj = hitObj.data();
+      out.hit_w = hitW.data();
+      check(mi355rt_render_host(scene.handle(), &cam, &st, &out));
       std::vector<ActionListener> fire;
       fire.swap(listeners_);
       for (ActionListener &l : fire) l(1, "finished");

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 --pmc passes of bench.py into per-kernel HBM bytes per launch.
 
-usage: hbm_traffic.py KEY FETCH_DIR WRITE_DIR [TCC_DIR] [--json PATH] > summary; also merges the result into
-PATH (default profiles/hbm_traffic.json) under KEY (bench.py reads roofline.traffic from profiles/hbm_traffic.json).
+usage: hbm_traffic.py KEY FETCH_DIR WRITE_DIR [TCC_DIR [SQ_DIR]] [--json PATH] > summary; also merges the result into
+PATH (default profiles/hbm_traffic.json) under KEY (bench.py reads roofline.traffic, valu_busy, lane_util and limiter from
+profiles/hbm_traffic.json -- and only while the kernel sources' hash stored with them is the hash of the tree it runs from).
 
 Rules (MI355X_MICROARCH.md, "HBM" and "rocprofv3 PMC slots"): FETCH_SIZE and WRITE_SIZE are collected in
 separate passes (3 + 2 TCC slots), both are in KiB, and on gfx950 FETCH_SIZE tallies each 128-byte
@@ -44,6 +45,7 @@ def main():
     fetch, n = per_kernel(fetch_dir)
     write, _ = per_kernel(write_dir)
     tcc = per_kernel(argv[3])[0] if len(argv) > 3 else {}
+    sq = per_kernel(argv[4])[0] if len(argv) > 4 else {}
     out = {}
     for k in fetch:
         rd = 2.0 * fetch[k]["FETCH_SIZE"] * 1024.0
@@ -56,9 +58,21 @@ def main():
             out[k]["tcc_ea0_rdreq_32b"] = t.get("TCC_EA0_RDREQ_32B_sum")
             hit, miss = t.get("TCC_HIT_sum", 0.0), t.get("TCC_MISS_sum", 0.0)
             out[k]["l2_hit_rate"] = round(hit / max(hit + miss, 1.0), 4)
+        q = sq.get(k)
+        if q:   # as tools/sq_summary.py: SIMD VALU busy = 4 cycles x SQ_INSTS_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines)
+            out[k]["valu_busy"] = round(4.0 * q["SQ_INSTS_VALU"] / 1024.0 / max(q["SQ_BUSY_CYCLES"] / 32.0, 1.0), 3)
+            out[k]["lane_util"] = round(q["SQ_THREAD_CYCLES_VALU"] / max(q["SQ_ACTIVE_INST_VALU"] * 64.0, 1.0), 3)
+            out[k]["limiter"] = "valu-issue" if out[k]["valu_busy"] >= 0.8 else ("hbm" if (rd + wr) > 0 and out[k].get("l2_hit_rate", 1.0) < 0.5 else "latency")
         print("%-14s launches=%-3d read=%8.1f MB (2 x FETCH_SIZE)  write=%8.1f MB  total=%8.1f MB%s"
               % (k, n[k], rd / 1e6, wr / 1e6, (rd + wr) / 1e6, "  L2 hit %.3f" % out[k]["l2_hit_rate"] if t else ""))
     allj = json.load(open(path)) if os.path.exists(path) else {}
+    import hashlib
+    import time
+    h = hashlib.sha1()
+    for name in ("trace_kernels.hip", "device_util.h", "layout.h", "walk_args.h"):   # bench.py kernel_sources_hash()
+        h.update(open(os.path.join(ROOT, "ray-tracer_amd", "csrc", name), "rb").read())
+    out["kernel_sources_sha1"] = h.hexdigest()
+    out["taken"] = time.strftime("%Y-%m-%d")
     allj[key] = out
     json.dump(allj, open(path, "w"), indent=1, sort_keys=True)
 

@@ -4,7 +4,7 @@
 #   e.g. tools/profile_round.sh r02_dragon dragon_1920x1080_4spp_n1
 #        tools/profile_round.sh r02_lucy lucy_3840x2160_16spp_n1 --model lucy --width 3840 --height 2160 --spp 16
 # One rocprofv3 run per counter pass (PMC slots: 8 SQ, 4 TCC; FETCH_SIZE takes 3 of them, WRITE_SIZE 2).
-tag=${1:-r02}; key=${2:-dragon_1920x1080_4spp_n1}; shift 2
+tag=${1:-r03}; key=${2:-dragon_1920x1080_4spp_n1}; shift 2
 R=${GRAFT_REPO_ROOT:-$PWD}
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
@@ -18,7 +18,7 @@ for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum 
   timeout -s KILL 200 rocprofv3 --pmc $ctrs -d $out/$name --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --frames-in-flight 1 "$@" > $out/$name.json 2> $out/$name.err || { tail -5 $out/$name.err; exit 1; }
   find $out/$name -name "*agent_info.csv" -delete
 done
-python3 $R/tools/hbm_traffic.py $key $out/fetch $out/write $out/tcc --json $out/hbm_traffic.json > $out/hbm_traffic.txt || exit 1
+python3 $R/tools/hbm_traffic.py $key $out/fetch $out/write $out/tcc $out/sq --json $out/hbm_traffic.json > $out/hbm_traffic.txt || exit 1
 python3 $R/tools/sq_summary.py $out/sq "$*" > $out/sq_counters.txt || exit 1
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 # the raw per-dispatch tables are large: only the summaries travel back
