@@ -552,6 +552,7 @@ def emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile)
     st = cam.frame_stats()
     rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
     one, rays_rank, sustained = [], [], []
+    pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.frames_in_flight))]   # the same streams for every rank's pipeline
     for r in ranks:
         cam.render_device(frame, stream=stream, tile_rank=r, tile_world=N, tile_size=tile, collect_stats=True)
         torch.cuda.synchronize()
@@ -572,7 +573,7 @@ def emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile)
         if args.frames_in_flight > 1:
             D = args.frames_in_flight
             pipe = tiles.FramePipeline(scene, lambda sc: rt.Camera(sc, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024),
-                                       W, H, r, 1, D, tile, dev, tile_world=N)
+                                       W, H, r, 1, D, tile, dev, tile_world=N, streams=pipe_streams)
             for _ in range(2 * D):
                 pipe.submit()
             pipe.drain()

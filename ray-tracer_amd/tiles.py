@@ -169,13 +169,17 @@ class FramePipeline:
     tensors in image order (on rank 0, or with world == 1)."""
 
     def __init__(self, scene, make_camera, width, height, rank=0, world=1, depth=2, tile=DEFAULT_TILE, device="cuda", tile_world=None,
-                 via_host=False):
+                 via_host=False, streams=None):
         self.rank, self.world, self.depth, self.tile = rank, world, depth, tile
         self.tile_world = world if tile_world is None else tile_world   # (tile_world != world: one rank's share of a larger run, for measurements)
         self.device = torch.device(device)
         self.views = [scene.view() for _ in range(depth)]
         self.cams = [make_camera(v) for v in self.views]
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        # HIP deals streams out over a few hardware queues (4 per process by default); two streams that share a queue run
+        # their frames one after the other, so a caller that builds many pipelines hands the same `depth` streams to each
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream(device=self.device) for _ in range(depth)]
+        if len(self.streams) != depth:
+            raise ValueError("FramePipeline: %d streams for depth %d" % (len(self.streams), depth))
         self.sharder = TileSharder(width, height, rank, world, tile, self.device, n_buffers=depth, via_host=via_host)
         full = rank == 0 or world == 1
         self.outs = [[torch.zeros((height, width, 3), dtype=torch.float32, device=self.device),
