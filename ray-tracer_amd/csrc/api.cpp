@@ -1848,23 +1848,14 @@ int mi355rt_ply_load(const char *path, uint32_t *n_vertices, uint32_t *n_faces, 
       PlyMesh m;
       const std::string err = read_ply(path, m);
       if (!err.empty()) return fail(MI355RT_E_IO, std::string(path) + ": " + err);
-      float *v = (float *) std::malloc(sizeof(float) * (m.vertices.size() ? m.vertices.size() : 1));
-      float *nr = (float *) std::malloc(sizeof(float) * (m.normals.size() ? m.normals.size() : 1));
-      int32_t *ix = (int32_t *) std::malloc(sizeof(int32_t) * (m.indices.size() ? m.indices.size() : 1));
-      if (!v || !nr || !ix) {
-         std::free(v);
-         std::free(nr);
-         std::free(ix);
-         return fail(MI355RT_E_MEMORY, "out of host memory");
-      }
-      if (!m.vertices.empty()) std::memcpy(v, m.vertices.data(), sizeof(float) * m.vertices.size());
-      if (!m.normals.empty()) std::memcpy(nr, m.normals.data(), sizeof(float) * m.normals.size());
-      if (!m.indices.empty()) std::memcpy(ix, m.indices.data(), sizeof(int32_t) * m.indices.size());
-      *n_vertices = (uint32_t) (m.vertices.size() / 3);
-      *n_faces = (uint32_t) (m.indices.size() / 3);
-      *vertices = v;
-      *normals = nr;
-      *indices = ix;
+      // the reader's arrays are malloc()ed: they go to the caller as they are (mi355rt_free)
+      *n_vertices = (uint32_t) m.n_vertices;
+      *n_faces = (uint32_t) m.n_faces;
+      *vertices = m.vertices;
+      *normals = m.normals;
+      *indices = m.indices;
+      m.vertices = m.normals = nullptr;
+      m.indices = nullptr;
       *has_normals = m.has_normals ? 1 : 0;
       return MI355RT_OK;
    });

@@ -16,6 +16,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace mi355rt {
 
@@ -82,21 +89,91 @@ bool to_int(const std::string &s, int32_t &v)
    return true;
 }
 
-uint32_t be32(const unsigned char *q) { return ((uint32_t) q[0] << 24) | ((uint32_t) q[1] << 16) | ((uint32_t) q[2] << 8) | (uint32_t) q[3]; }
+uint32_t be32(const unsigned char *q)
+{
+   uint32_t v;
+   std::memcpy(&v, q, 4);
+   return __builtin_bswap32(v);
+}
+
+// The file as one read-only range: mapped (a 533 MB Lucy-class file is neither read into a buffer nor copied while one
+// grows), or read whole where mapping is refused (pipes, odd file systems).
+struct FileBytes {
+   const char *p = nullptr;
+   size_t n = 0;
+   void *map = nullptr;
+   std::string owned;
+   ~FileBytes()
+   {
+      if (map) munmap(map, n);
+   }
+   bool open(const char *path)
+   {
+      const int fd = ::open(path, O_RDONLY);
+      if (fd < 0) return false;
+      struct stat sb;
+      if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+         void *m = mmap(nullptr, (size_t) sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+         if (m != MAP_FAILED) {
+            (void) madvise(m, (size_t) sb.st_size, MADV_SEQUENTIAL);
+            map = m;
+            p = (const char *) m;
+            n = (size_t) sb.st_size;
+            ::close(fd);
+            return true;
+         }
+      }
+      char chunk[1 << 16];
+      ssize_t got;
+      while ((got = ::read(fd, chunk, sizeof(chunk))) > 0) owned.append(chunk, (size_t) got);
+      ::close(fd);
+      p = owned.data();
+      n = owned.size();
+      return true;
+   }
+};
+
+// fn(first, last) over [0, n) on the threads this process may use (at most 16): the binary body is fixed-size records
+template <class F>
+void in_ranges(size_t n, F fn)
+{
+   int cores = 1;
+   cpu_set_t set;
+   if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
+   const size_t by_size = n / (1u << 18) + 1;   // a thread per quarter million records at most
+   const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t) std::max(cores, 1), 16), by_size));
+   if (nt == 1) {
+      fn((size_t) 0, n);
+      return;
+   }
+   std::vector<std::thread> th;
+   for (size_t t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+   for (std::thread &x : th) x.join();
+}
 
 }   // namespace
 
+void PlyMesh::clear()
+{
+   std::free(vertices);
+   std::free(normals);
+   std::free(indices);
+   vertices = normals = nullptr;
+   indices = nullptr;
+   n_vertices = n_faces = 0;
+   has_normals = false;
+}
+
 std::string read_ply(const char *path, PlyMesh &out)
 {
-   std::FILE *f = std::fopen(path, "rb");
-   if (!f) return "cannot open file";
-   std::string data;
-   {
-      char chunk[1 << 16];
-      size_t got;
-      while ((got = std::fread(chunk, 1, sizeof(chunk), f)) > 0) data.append(chunk, got);
-   }
-   std::fclose(f);
+   FileBytes file;
+   if (!file.open(path)) return "cannot open file";
+   struct {
+      const char *p;
+      size_t n;
+      const char *data() const { return p; }
+      size_t size() const { return n; }
+   } data { file.p, file.n };
 
    Cursor cur { data.data(), data.data() + data.size() };
    const char *b, *e;
@@ -157,11 +234,20 @@ std::string read_ply(const char *path, PlyMesh &out)
       if ((size_t) n_faces * 13 > body_bytes - (size_t) n_vertices * (size_t) slot * 4) return "file ends inside the face block";
    }
 
-   out = PlyMesh();
+   // (binary: every element is written below; ASCII: face rows the file does not have stay zero; normals the file does not
+   // have are zeros: calloc's untouched pages cost nothing)
+   out.clear();
    out.has_normals = has_n;
-   out.vertices.assign(3 * (size_t) n_vertices, 0.0f);
-   out.normals.assign(3 * (size_t) n_vertices, 0.0f);
-   out.indices.assign(3 * (size_t) n_faces, 0);
+   out.n_vertices = (size_t) n_vertices;
+   out.n_faces = (size_t) n_faces;
+   const size_t nv3 = std::max<size_t>(3 * (size_t) n_vertices, 1), nf3 = std::max<size_t>(3 * (size_t) n_faces, 1);
+   out.vertices = (float *) (ascii ? std::calloc(nv3, sizeof(float)) : std::malloc(nv3 * sizeof(float)));
+   out.normals = (float *) (ascii || !has_n ? std::calloc(nv3, sizeof(float)) : std::malloc(nv3 * sizeof(float)));
+   out.indices = (int32_t *) (ascii ? std::calloc(nf3, sizeof(int32_t)) : std::malloc(nf3 * sizeof(int32_t)));
+   if (!out.vertices || !out.normals || !out.indices) {
+      out.clear();
+      return "out of host memory";
+   }
 
    if (ascii) {
       for (int32_t i = 0; i < n_vertices; i++) {
@@ -195,25 +281,33 @@ std::string read_ply(const char *path, PlyMesh &out)
    const size_t vbytes = (size_t) n_vertices * (size_t) slot * 4;
    const size_t fbytes = (size_t) n_faces * 13;
    if ((size_t) (qe - q) < vbytes) return "file ends inside the vertex block";
-   const unsigned char *u = (const unsigned char *) q;
-   for (int32_t i = 0; i < n_vertices; i++, u += (size_t) slot * 4) {
-      const int src[3] = { sx, sy, sz };
-      for (int c = 0; c < 3; c++) {
-         const uint32_t bits = be32(u + 4 * (size_t) src[c]);
-         std::memcpy(&out.vertices[3 * (size_t) i + c], &bits, 4);
-      }
-      if (has_n) {
-         const int nsrc[3] = { snx, sny, snz };
+   const unsigned char *u0 = (const unsigned char *) q;
+   const size_t stride = (size_t) slot * 4;
+   float *vout = out.vertices, *nout = out.normals;
+   in_ranges((size_t) n_vertices, [=](size_t first, size_t last) {
+      const int src[3] = { sx, sy, sz }, nsrc[3] = { snx, sny, snz };
+      const unsigned char *u = u0 + first * stride;
+      for (size_t i = first; i < last; i++, u += stride) {
          for (int c = 0; c < 3; c++) {
-            const uint32_t bits = be32(u + 4 * (size_t) nsrc[c]);
-            std::memcpy(&out.normals[3 * (size_t) i + c], &bits, 4);
+            const uint32_t bits = be32(u + 4 * (size_t) src[c]);
+            std::memcpy(vout + 3 * i + c, &bits, 4);
+         }
+         if (has_n) {
+            for (int c = 0; c < 3; c++) {
+               const uint32_t bits = be32(u + 4 * (size_t) nsrc[c]);
+               std::memcpy(nout + 3 * i + c, &bits, 4);
+            }
          }
       }
-   }
-   if ((size_t) ((const unsigned char *) qe - u) < fbytes) return "file ends inside the face block";
-   for (int32_t i = 0; i < n_faces; i++, u += 13) {
-      for (int c = 0; c < 3; c++) out.indices[3 * (size_t) i + c] = (int32_t) be32(u + 1 + 4 * c);
-   }
+   });
+   const unsigned char *f0 = u0 + vbytes;
+   if ((size_t) ((const unsigned char *) qe - f0) < fbytes) return "file ends inside the face block";
+   int32_t *iout = out.indices;
+   in_ranges((size_t) n_faces, [=](size_t first, size_t last) {
+      const unsigned char *u = f0 + first * 13;
+      for (size_t i = first; i < last; i++, u += 13)
+         for (int c = 0; c < 3; c++) iout[3 * i + c] = (int32_t) be32(u + 1 + 4 * c);
+   });
    return std::string();
 }
 

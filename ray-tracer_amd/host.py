@@ -23,6 +23,8 @@ and shading all happen behind include/mi355rt.h.
 """
 import ctypes as C
 
+import time
+
 import numpy as np
 
 from . import _abi
@@ -289,16 +291,18 @@ def load_ply(path):
     pv, pn, pi = _abi.c_float_p(), _abi.c_float_p(), _abi.c_int32_p()
     if isinstance(path, str):
         path = path.encode()
+    t0 = time.perf_counter()
     _abi.check(lib.mi355rt_ply_load(path, C.byref(nv), C.byref(nf), C.byref(pv), C.byref(pn), C.byref(pi), C.byref(hn)))
+    load_ply.last_parse_s = time.perf_counter() - t0   # the library's share (the copies into numpy arrays below are this wrapper's)
     try:
         v = np.ctypeslib.as_array(pv, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy().reshape(-1, 3)
-        n = np.ctypeslib.as_array(pn, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy().reshape(-1, 3)
+        n = np.ctypeslib.as_array(pn, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy().reshape(-1, 3) if hn.value else None
         i = np.ctypeslib.as_array(pi, shape=(max(nf.value, 1) * 3,))[: nf.value * 3].copy().reshape(-1, 3)
     finally:
         lib.mi355rt_free(pv)
         lib.mi355rt_free(pn)
         lib.mi355rt_free(pi)
-    return v, i, (n if hn.value else None)
+    return v, i, n
 
 
 def compute_normals(vertices, indices):
