@@ -27,6 +27,7 @@
 #include "layout.h"
 #include "ply_reader.hpp"
 #include "scene_build.hpp"
+#include "host_parallel.hpp"
 #include "switches.hpp"
 
 using namespace mi355rt;
@@ -1035,7 +1036,15 @@ int mi355rt_scene_create_objects(const mi355rt_object_desc *objects, uint32_t n_
             if (md.compute_kdtree != 0) bo_obj.use_kdtree = md.compute_kdtree > 0;
             bool gpu_build = allow_gpu_build && bo_obj.use_kdtree && bo.max_depth >= 1 && md.n_faces > (uint32_t) std::max(bo.max_children, 0) &&
                              md.vertices && md.indices;
-            for (size_t v = 0; gpu_build && v < 3 * (size_t) md.n_vertices; v++) gpu_build = std::isfinite(md.vertices[v]);
+            if (gpu_build) {
+               std::vector<char> finite(host_threads_for(3 * (size_t) md.n_vertices, (size_t) 1 << 20), 1);
+               in_ranges(3 * (size_t) md.n_vertices, (size_t) 1 << 20, [&](size_t t, size_t first, size_t last) {
+                  bool ok = true;
+                  for (size_t v = first; ok && v < last; v++) ok = std::isfinite(md.vertices[v]);
+                  finite[t] = ok ? 1 : 0;
+               });
+               for (char ok : finite) gpu_build = gpu_build && ok != 0;
+            }
             bo_obj.build_tree = !gpu_build;
             bo_obj.synth_normals = !gpu_build;   // (a part built on the GPU gets its normals there too)
             BuiltObject bo_out;

@@ -11,15 +11,14 @@
 // error string instead of exiting the process (TriangleMesh.java:90-93).
 #include "ply_reader.hpp"
 
+#include "host_parallel.hpp"
+
 #include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <thread>
-
 #include <fcntl.h>
-#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -132,24 +131,6 @@ struct FileBytes {
       return true;
    }
 };
-
-// fn(first, last) over [0, n) on the threads this process may use (at most 16): the binary body is fixed-size records
-template <class F>
-void in_ranges(size_t n, F fn)
-{
-   int cores = 1;
-   cpu_set_t set;
-   if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
-   const size_t by_size = n / (1u << 18) + 1;   // a thread per quarter million records at most
-   const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t) std::max(cores, 1), 16), by_size));
-   if (nt == 1) {
-      fn((size_t) 0, n);
-      return;
-   }
-   std::vector<std::thread> th;
-   for (size_t t = 0; t < nt; t++) th.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
-   for (std::thread &x : th) x.join();
-}
 
 }   // namespace
 
@@ -284,7 +265,7 @@ std::string read_ply(const char *path, PlyMesh &out)
    const unsigned char *u0 = (const unsigned char *) q;
    const size_t stride = (size_t) slot * 4;
    float *vout = out.vertices, *nout = out.normals;
-   in_ranges((size_t) n_vertices, [=](size_t first, size_t last) {
+   in_ranges((size_t) n_vertices, (size_t) 1 << 18, [=](size_t, size_t first, size_t last) {
       const int src[3] = { sx, sy, sz }, nsrc[3] = { snx, sny, snz };
       const unsigned char *u = u0 + first * stride;
       for (size_t i = first; i < last; i++, u += stride) {
@@ -303,7 +284,7 @@ std::string read_ply(const char *path, PlyMesh &out)
    const unsigned char *f0 = u0 + vbytes;
    if ((size_t) ((const unsigned char *) qe - f0) < fbytes) return "file ends inside the face block";
    int32_t *iout = out.indices;
-   in_ranges((size_t) n_faces, [=](size_t first, size_t last) {
+   in_ranges((size_t) n_faces, (size_t) 1 << 18, [=](size_t, size_t first, size_t last) {
       const unsigned char *u = f0 + first * 13;
       for (size_t i = first; i < last; i++, u += 13)
          for (int c = 0; c < 3; c++) iout[3 * i + c] = (int32_t) be32(u + 1 + 4 * c);

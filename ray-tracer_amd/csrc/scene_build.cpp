@@ -14,6 +14,8 @@
 // DFS pre-order, and leaf faces are appended to one slot array in DFS order.
 #include "scene_build.hpp"
 
+#include "host_parallel.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -386,24 +388,57 @@ std::string build_object(const float *vertices, uint32_t n_vertices, const float
    if ((n_vertices && !vertices) || (n_faces && !indices)) return "null vertex or index array";
    if (opts.max_depth < 0 || opts.max_depth > MAX_TREE_DEPTH) return "max_depth outside [0, " + std::to_string(MAX_TREE_DEPTH) + "]";
    if (opts.max_children < 0) return "max_children must be >= 0";
-   for (size_t i = 0; i < 3 * (size_t) n_faces; i++) {
-      if (indices[i] < 0 || (uint32_t) indices[i] >= n_vertices) return "face index out of range at element " + std::to_string(i);
+   {   // (flat passes over tens of millions of elements: on the host threads there are; the first bad element is reported
+       // and the bounds are combined with Java's min / max, so the answers are those of the one-thread loops)
+      constexpr size_t NONE = ~(size_t) 0;
+      std::vector<size_t> bad(host_threads_for(3 * (size_t) n_faces, (size_t) 1 << 20), NONE);
+      in_ranges(3 * (size_t) n_faces, (size_t) 1 << 20, [&](size_t t, size_t first, size_t last) {
+         for (size_t i = first; i < last; i++)
+            if (indices[i] < 0 || (uint32_t) indices[i] >= n_vertices) {
+               bad[t] = i;
+               return;
+            }
+      });
+      for (size_t b : bad)
+         if (b != NONE) return "face index out of range at element " + std::to_string(b);
    }
 
    out = BuiltObject();
-   out.normals.resize(3 * (size_t) n_vertices);
-   if (normals) std::copy(normals, normals + 3 * (size_t) n_vertices, out.normals.begin());
-   else if (opts.synth_normals) synthesise_normals(vertices, n_vertices, indices, n_faces, out.normals.data());
-   else out.normals.clear();
-
-   for (int c = 0; c < 3; c++) {
-      out.bmin[c] = jm::kFloatMax;
-      out.bmax[c] = -jm::kFloatMax;
+   // (a part the GPU builds gets or keeps its normals there: opts.synth_normals is off and nothing here reads them)
+   if (opts.synth_normals) {
+      out.normals.resize(3 * (size_t) n_vertices);
+      if (normals) std::copy(normals, normals + 3 * (size_t) n_vertices, out.normals.begin());
+      else synthesise_normals(vertices, n_vertices, indices, n_faces, out.normals.data());
    }
-   for (uint32_t v = 0; v < n_vertices; v++) {
+
+   {
+      struct Box {
+         float lo[3], hi[3];
+      };
+      std::vector<Box> boxes(host_threads_for((size_t) n_vertices, (size_t) 1 << 19));
+      in_ranges((size_t) n_vertices, (size_t) 1 << 19, [&](size_t t, size_t first, size_t last) {
+         Box b;
+         for (int c = 0; c < 3; c++) {
+            b.lo[c] = jm::kFloatMax;
+            b.hi[c] = -jm::kFloatMax;
+         }
+         for (size_t v = first; v < last; v++) {
+            for (int c = 0; c < 3; c++) {
+               b.lo[c] = jm::fmin_java(vertices[3 * v + c], b.lo[c]);
+               b.hi[c] = jm::fmax_java(vertices[3 * v + c], b.hi[c]);
+            }
+         }
+         boxes[t] = b;
+      });
       for (int c = 0; c < 3; c++) {
-         out.bmin[c] = jm::fmin_java(vertices[3 * (size_t) v + c], out.bmin[c]);
-         out.bmax[c] = jm::fmax_java(vertices[3 * (size_t) v + c], out.bmax[c]);
+         out.bmin[c] = jm::kFloatMax;
+         out.bmax[c] = -jm::kFloatMax;
+      }
+      for (const Box &b : boxes) {   // in range order: min / max of the same values, NaN sticky as in the one loop
+         for (int c = 0; c < 3; c++) {
+            out.bmin[c] = jm::fmin_java(b.lo[c], out.bmin[c]);
+            out.bmax[c] = jm::fmax_java(b.hi[c], out.bmax[c]);
+         }
       }
    }
    out.shadow_distance =
