@@ -552,7 +552,7 @@ def emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile)
     torch.cuda.synchronize()
     st = cam.frame_stats()
     rays = st["primary_rays"] + st["shadow_rays"] + st["secondary_rays"]
-    one, rays_rank, sustained = [], [], []
+    one, rays_rank, sustained, kernels = [], [], [], []
     pipe_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.frames_in_flight))]   # the same streams for every rank's pipeline
     for r in ranks:
         cam.render_device(frame, stream=stream, tile_rank=r, tile_world=N, tile_size=tile, collect_stats=True)
@@ -571,6 +571,12 @@ def emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile)
             torch.cuda.synchronize()   # one frame at a time
             ms.append(a.elapsed_time(b))
         one.append(float(np.median(ms)))
+        cam.kernel_profile(reset=True)   # where a share's time goes: its kernels (HIP events around each launch), the rest is launch gaps
+        for _ in range(3):
+            cam.render_device(frame, stream=stream, tile_rank=r, tile_world=N, tile_size=tile, collect_times=True)
+        torch.cuda.synchronize()
+        kp = cam.kernel_profile(reset=True)
+        kernels.append({k: round(v["ms"] / 3.0, 4) for k, v in kp.items() if v["launches"]})
         if args.frames_in_flight > 1:
             D = args.frames_in_flight
             pipe = tiles.FramePipeline(scene, lambda sc: rt.Camera(sc, args.spp, args.brdf_samples, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=2024),
@@ -587,7 +593,8 @@ def emulate_shares(rt, tiles, args, scene, cam, frame, stream, dev, label, tile)
             pipe.close()
     res = {"emulated": True, "note": "one GPU rendering each rank's tiles of an N-rank frame in turn, before the exchange step: not a bench result",
            "workload": "%s %dx%d, %d spp" % (label, W, H, args.spp), "world": N, "tile": tile, "ranks_measured": ranks, "rays_per_frame": int(rays),
-           "rank_rays": rays_rank, "rank_ms": [round(x, 4) for x in one], "max_ms": round(max(one), 4), "mean_ms": round(float(np.mean(one)), 4)}
+           "rank_rays": rays_rank, "rank_ms": [round(x, 4) for x in one], "max_ms": round(max(one), 4), "mean_ms": round(float(np.mean(one)), 4),
+           "rank_kernel_ms": kernels}
     if sustained:
         res.update(frames_in_flight=args.frames_in_flight, rank_sustained_ms=[round(x, 4) for x in sustained], max_sustained_ms=round(max(sustained), 4))
     return res
