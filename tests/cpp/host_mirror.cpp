@@ -2,7 +2,8 @@
 // RayTracer.java / RayTracerInterface.java drive the reference; the pytest wrappers compare its output with the
 // oracle (tests/test_cpp_host.py).
 //   host_mirror abi
-//   host_mirror render <mesh.ply> <width> <height> <multiSamples> <seed> <fov> <out.bin>
+//   host_mirror render <mesh.ply> <width> <height> <multiSamples> <seed> <fov> <out.bin> [ranks]
+//       ranks > 0: the scene gets a device list that names GPU 0 that many times (Scene::setDevices: the N-rank path on one GPU)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +78,7 @@ static int write_frame(const Camera &camera, int W, int H, const char *path)
    std::fwrite(camera.hitId.data(), sizeof(int32_t), (size_t) W * H, f);
    std::fwrite(camera.hitW.data(), sizeof(float), (size_t) W * H, f);
    std::fwrite(camera.hitObj.data(), sizeof(int32_t), (size_t) W * H, f);
+   std::fwrite(camera.image.data(), sizeof(uint32_t), (size_t) W * H, f);   // Camera.image
    std::fclose(f);
    std::printf("RENDER_OK %dx%d pixel(0,0)=%g\n", W, H, camera.getPixel(0, 0)[0]);
    return 0;
@@ -103,16 +105,25 @@ static int run_whitted(char **argv)
    return write_frame(camera, W, H, argv[6]);
 }
 
-static int run_render(char **argv)
+static int run_render(int argc, char **argv)
 {
    const std::string ply = argv[2];
    const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), ms = std::atoi(argv[5]);
    const unsigned long long seed = std::strtoull(argv[6], nullptr, 10);
    const float fov = (float) std::atof(argv[7]);
+   const int ranks = argc > 9 ? std::atoi(argv[9]) : 0;
    Light light({ 0.f, 100.f, 100.f }, { 0.3f, 0.3f, 0.3f }, { 0.5f, 0.5f, 0.9f });     // RayTracer.java:106
    TriangleMesh mesh(ply, ColorInformation({ 0.9f, 0.9f, 0.9f }), true);
    PhongLightingModel model(light, { &mesh });
    Scene scene({ &mesh }, light, { 0.f, 0.f, 0.f }, model, fov);
+   if (ranks > 0) {
+      scene.setDevices(std::vector<int32_t>((size_t) ranks, 0));
+      const mi355rt_multi_info info = scene.multiInfo();
+      std::printf("ranks %u transport %d\n", info.n_ranks, info.transport);
+      if ((int) info.n_ranks != ranks) return 1;
+   }
+   const std::array<double, 7> bs = scene.buildSeconds();
+   std::printf("build seconds %.4f %.4f %.4f %.4f %.4f %.4f %.4f\n", bs[0], bs[1], bs[2], bs[3], bs[4], bs[5], bs[6]);
    Camera camera(scene, ms, 1, RTStatics::NEAR_PLANE, W, H);
    camera.rngSeed = seed;
    int fired = 0;
@@ -129,7 +140,7 @@ int main(int argc, char **argv)
 {
    try {
       if (argc >= 2 && std::strcmp(argv[1], "abi") == 0) return run_abi();
-      if (argc >= 9 && std::strcmp(argv[1], "render") == 0) return run_render(argv);
+      if (argc >= 9 && std::strcmp(argv[1], "render") == 0) return run_render(argc, argv);
       if (argc >= 7 && std::strcmp(argv[1], "whitted") == 0) return run_whitted(argv);
    } catch (const std::exception &e) {
       std::printf("exception: %s\n", e.what());

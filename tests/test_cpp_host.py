@@ -83,3 +83,32 @@ def test_cpp_mirror_whitted_scene_matches_oracle(orc, tmp_path):
     assert ids_equal and w_equal and max_rel <= 1e-3, (n_diff, max_rel)
     assert set(np.unique(o["hit_obj"])) == {-1, 0, 1, 2}
     osc.close()
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_device_list_and_8bit_image(rt, tmp_path):
+    """Scene::setDevices from C++ (GPU 0 named twice: two ranks, peer copies) renders the one-GPU frame bit for bit, and
+    Camera.image (mi355rt_render_host's argb8 output, Camera.java:103-107) is the 8-bit pack of Camera.pixels."""
+    v, i = rt.meshgen.blob(9000, span=0.156, seed=4)
+    ply = str(tmp_path / "mesh.ply")
+    rt.meshgen.write_ply(ply, v, i, binary=True)
+    W, H, ms, seed, fov = 208, 152, 2, 11, 15.0
+    frames = []
+    for ranks in (0, 2):
+        out = str(tmp_path / ("frame%d.bin" % ranks))
+        r = _run("render", ply, W, H, ms, seed, fov, out, ranks)
+        assert r.returncode == 0 and "RENDER_OK" in r.stdout, r.stdout
+        if ranks:
+            assert "ranks 2 transport 1" in r.stdout, r.stdout   # MI355RT_TRANSPORT_PEER
+        assert "build seconds" in r.stdout
+        frames.append(np.fromfile(out, dtype=np.uint32))
+    assert frames[0].size == 8 + 7 * W * H
+    assert np.array_equal(frames[0], frames[1])
+    body = frames[0][8:]
+    rgb = body[: 3 * W * H].view(np.float32).reshape(H, W, 3)
+    image = body[6 * W * H: 7 * W * H].reshape(H, W)
+    c = np.clip(rgb, np.float32(0.0), np.float32(1.0))   # Camera.java:103-107: new Color(bound(r), bound(g), bound(b)).getRGB()
+    q = ((c * np.float32(255.0)).astype(np.float64) + 0.5).astype(np.int64).astype(np.uint32) & np.uint32(255)   # Color(float...): (int) (x * 255 + 0.5)
+    expect = np.uint32(0xFF000000) | (q[..., 0] << np.uint32(16)) | (q[..., 1] << np.uint32(8)) | q[..., 2]
+    assert np.array_equal(image, expect)
+    assert (image != 0xFF000000).mean() > 0.05
