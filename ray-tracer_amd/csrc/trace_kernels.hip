@@ -431,6 +431,54 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void generate_kernel(const FrameArg
    }
 }
 
+// min / max as the instructions themselves.  Through fminf / fmaxf the compiler first quiets every operand it cannot prove
+// free of signalling NaNs (a v_max_f32 x, x, x each: twelve of them in the packed node step, whose operands are halves of
+// packed products); these are for values that are known not to be NaN at all (the packed step's argument), where
+// v_min / v_max / v_min3 / v_max3 give what fminf / fmaxf give.
+#ifndef WALK_RAW_MINMAX
+#define WALK_RAW_MINMAX 1
+#endif
+__device__ __forceinline__ float raw_min(float a, float b)
+{
+#if WALK_RAW_MINMAX
+   float r;
+   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   return r;
+#else
+   return fminf(a, b);
+#endif
+}
+__device__ __forceinline__ float raw_max(float a, float b)
+{
+#if WALK_RAW_MINMAX
+   float r;
+   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+   return r;
+#else
+   return fmaxf(a, b);
+#endif
+}
+__device__ __forceinline__ float raw_min3(float a, float b, float c)
+{
+#if WALK_RAW_MINMAX
+   float r;
+   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+   return r;
+#else
+   return fminf(fminf(a, b), c);
+#endif
+}
+__device__ __forceinline__ float raw_max3(float a, float b, float c)
+{
+#if WALK_RAW_MINMAX
+   float r;
+   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+   return r;
+#else
+   return fmaxf(fmaxf(a, b), c);
+#endif
+}
+
 // ---------------------------------------------------------------- the walker
 // One kernel walks every kind of ray:
 //   MODE_CLOSEST     Camera.getClosestIntersection (Camera.java:193-215) for the rays of a queue;
@@ -1052,10 +1100,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                      const f2 ddy = { fmaxf(fmaxf(ay.x, -by.x), 0.0f), fmaxf(fmaxf(ay.y, -by.y), 0.0f) };
                      const f2 ddz = { fmaxf(fmaxf(az.x, -bz.x), 0.0f), fmaxf(fmaxf(az.y, -bz.y), 0.0f) };
                      const f2 d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-                     tl = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
-                     tr = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
-                     const float hl = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
-                     const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
+                     tl = raw_max3(raw_min(t1x.x, t2x.x), raw_min(t1y.x, t2y.x), raw_min(t1z.x, t2z.x));
+                     tr = raw_max3(raw_min(t1x.y, t2x.y), raw_min(t1y.y, t2y.y), raw_min(t1z.y, t2z.y));
+                     const float hl = raw_min3(raw_max(t1x.x, t2x.x), raw_max(t1y.x, t2y.x), raw_max(t1z.x, t2z.x));
+                     const float hr = raw_min3(raw_max(t1x.y, t2x.y), raw_max(t1y.y, t2y.y), raw_max(t1z.y, t2z.y));
                      lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
                      rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
                      if (MODE == MODE_SHADOW && !st.redo) {
@@ -1286,10 +1334,10 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
             const f2 ddy = { fmaxf(fmaxf(ay.x, -by.x), 0.0f), fmaxf(fmaxf(ay.y, -by.y), 0.0f) };
             const f2 ddz = { fmaxf(fmaxf(az.x, -bz.x), 0.0f), fmaxf(fmaxf(az.y, -bz.y), 0.0f) };
             const f2 d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-            tl = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
-            tr = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
-            const float hl = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
-            const float hr = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
+            tl = raw_max3(raw_min(t1x.x, t2x.x), raw_min(t1y.x, t2y.x), raw_min(t1z.x, t2z.x));
+            tr = raw_max3(raw_min(t1x.y, t2x.y), raw_min(t1y.y, t2y.y), raw_min(t1z.y, t2z.y));
+            const float hl = raw_min3(raw_max(t1x.x, t2x.x), raw_max(t1y.x, t2y.x), raw_max(t1z.x, t2z.x));
+            const float hr = raw_min3(raw_max(t1x.y, t2x.y), raw_max(t1y.y, t2y.y), raw_max(t1z.y, t2z.y));
             lok = nd.x != LINK_NONE && tl <= hl && tl < farp && hl > nearp && !(d2.x > lim2);
             rok = nd.y != LINK_NONE && tr <= hr && tr < farp && hr > nearp && !(d2.y > lim2);
             if (MODE == MODE_SHADOW && !st.redo) {   // hopeless boxes (device_util.h, shortcut 2); st.plain implies finite boxes
