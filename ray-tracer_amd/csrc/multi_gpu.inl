@@ -403,18 +403,7 @@ int rank_frame(Multi *m, int r, const mi355rt_camera *cam, const mi355rt_setting
    RankCtx &rk = m->ranks[(size_t) r];
    const int world = (int) m->ranks.size();
    const bool into_recv = r == 0 && !self_send;
-   float *block = into_recv ? m->recv : rk.block;
-   if (!into_recv && rk.block_words < 6 * n) {
-      if (rk.block) {
-         HIP_TRY(hipStreamSynchronize(rk.stream));
-         (void) hipFree(rk.block);
-      }
-      rk.block = nullptr;
-      rk.block_words = 0;
-      HIP_TRY(hipMalloc((void **) &rk.block, 6 * n * sizeof(float)));
-      rk.block_words = 6 * n;
-      block = rk.block;
-   }
+   float *block = into_recv ? m->recv : rk.block;   // (sized by render_multi before anything was posted)
    mi355rt_settings st = *st_in;
    st.tile_size = tile;
    st.tile_rank = r;
@@ -422,18 +411,28 @@ int rank_frame(Multi *m, int r, const mi355rt_camera *cam, const mi355rt_setting
    st.tile_compact = 1;
    FrameArgs p;
    long long n_micro = 0;
+   // (what this checks is the same on every rank -- camera, settings, the scene's description -- so either every rank goes
+   // on to the exchange or none does)
    if (int rc = fill_frame_args(rk.s, cam, &st, p, n_micro)) return rc;
    p.rgb = block;
    p.argb8 = nullptr;
    p.hit_id = (int32_t *) (block + 3 * n);
    p.hit_obj = (int32_t *) (block + 4 * n);
    p.hit_w = block + 5 * n;
-   HIP_TRY(hipStreamWaitEvent(rk.stream, m->started, 0));                               // after what the caller's stream held
-   if (m->unpacked_recorded) HIP_TRY(hipStreamWaitEvent(rk.stream, m->unpacked, 0));    // the receive area is free again
-   HIP_TRY(hipEventRecord(rk.t_begin, rk.stream));
-   if (int rc = run_frame(rk.s, p, n_micro, (st.collect_stats & MI355RT_COLLECT_TIMES) != 0, rk.stream)) return rc;
-   HIP_TRY(hipEventRecord(rk.t_end, rk.stream));
-   rk.timed = true;
+   // The frame itself can fail on ONE rank (its scratch grows on a first, larger frame: device memory).  The exchange below
+   // is posted all the same: a send that never came would leave rank 0's receives, and a receive that never came the other
+   // ranks' sends, waiting for good (RCCL has no time-outs).  The call then fails with the rank's error.
+   const int frame_rc = [&]() -> int {
+      HIP_TRY(hipStreamWaitEvent(rk.stream, m->started, 0));                               // after what the caller's stream held
+      if (m->unpacked_recorded) HIP_TRY(hipStreamWaitEvent(rk.stream, m->unpacked, 0));    // the receive area is free again
+      HIP_TRY(hipEventRecord(rk.t_begin, rk.stream));
+      if (int rc = run_frame(rk.s, p, n_micro, (st.collect_stats & MI355RT_COLLECT_TIMES) != 0, rk.stream)) return rc;
+      HIP_TRY(hipEventRecord(rk.t_end, rk.stream));
+      rk.timed = true;
+      return MI355RT_OK;
+   }();
+   const std::string frame_err = frame_rc != MI355RT_OK ? g_error : std::string();
+   const int exchange_rc = [&]() -> int {
    MultiShared *sh = m->shared;
    if (sh->transport == TRANSPORT_RCCL) {
       const RcclApi &api = rccl_api();
@@ -454,6 +453,9 @@ int rank_frame(Multi *m, int r, const mi355rt_camera *cam, const mi355rt_setting
       HIP_TRY(hipEventRecord(rk.sent, rk.stream));
    }
    return MI355RT_OK;
+   }();
+   if (frame_rc != MI355RT_OK) return fail(frame_rc, frame_err);
+   return exchange_rc;
 }
 
 // mi355rt_render_device on a handle with a device list; s->device is current
@@ -487,6 +489,20 @@ int render_multi(mi355rt_scene *s, const mi355rt_camera *cam, const mi355rt_sett
       HIP_TRY(hipMalloc((void **) &m->recv, (size_t) world * 6 * n * sizeof(float)));
       m->recv_words = (size_t) world * 6 * n;
       m->unpacked_recorded = false;
+   }
+   for (int r = self_send ? 0 : 1; r < world; r++) {   // every rank's block, before anything is posted (see rank_frame)
+      RankCtx &rk = m->ranks[(size_t) r];
+      if (rk.block_words >= 6 * n) continue;
+      DeviceScope scope(rk.device);
+      if (!scope.ok()) return fail(MI355RT_E_DEVICE, "cannot select HIP device " + std::to_string(rk.device));
+      if (rk.block) {
+         HIP_TRY(hipStreamSynchronize(rk.stream));
+         (void) hipFree(rk.block);
+      }
+      rk.block = nullptr;
+      rk.block_words = 0;
+      HIP_TRY(hipMalloc((void **) &rk.block, 6 * n * sizeof(float)));
+      rk.block_words = 6 * n;
    }
    HIP_TRY(hipEventRecord(m->started, stream));
    for (int r = 1; r < world; r++) sh->workers[(size_t) r - 1]->post([=]() -> int { return rank_frame(m, r, cam, st, tile, n, false); });
