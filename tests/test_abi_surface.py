@@ -67,3 +67,16 @@ def test_argument_errors_are_reported(rt):
     assert lib.mi355rt_scene_create(None, 0, None, None) == rt._abi.E_ARG
     assert b"null" in lib.mi355rt_last_error()
     assert lib.mi355rt_ply_load(b"/nonexistent/file.ply", *[None] * 6) == rt._abi.E_ARG
+
+
+def test_debug_switch_knows_its_names(rt):
+    """mi355rt_debug_switch (no GPU needed): every documented switch is accepted with and without the MI355RT_ prefix, a
+    value of None restores the default, name None restores the environment's values, an unknown name is MI355RT_E_ARG."""
+    for name in ("BUILDER", "BUILD_TIMING", "FUSE_SHADOW", "PASS_SLOTS_LOG2", "BIG_LEAVES", "BLOCKS_PER_CU", "BLOCKS_PER_CU_SHADOW", "TRIM",
+                 "TRIM_PRIMARY_X2", "TRIM_SHADOW_X2", "SPREAD_SL", "SPREAD_BL", "SPREAD_PRIMARY_MAX", "TRANSPORT", "BOUNCE_SYNC", "GPU_GROUP"):
+        rt.debug_switch(name, 1 if name not in ("BUILDER", "TRANSPORT") else ("host" if name == "BUILDER" else "peer"))
+        rt.debug_switch("MI355RT_" + name, None)
+    rt.debug_switch(None, None)
+    with pytest.raises(rt._abi.Mi355rtError) as e:
+        rt.debug_switch("NO_SUCH_SWITCH", 1)
+    assert "unknown switch" in str(e.value)
