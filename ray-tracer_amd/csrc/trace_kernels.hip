@@ -544,6 +544,9 @@ enum { ROLE_IDLE = 0, ROLE_OWNER = 1, ROLE_HELPER = 2 };
 #ifndef WALK_NODE_REPS
 #define WALK_NODE_REPS 1
 #endif
+#ifndef WALK_FLAT_CONTROL
+#define WALK_FLAT_CONTROL 1
+#endif
 #ifndef WALK_SIDE_MIN
 #define WALK_SIDE_MIN 12   // (measured flat from 1 to 28 on the bench frame)
 #endif
@@ -1143,6 +1146,46 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                   }
                   // A leaf child goes to the leaf side if that is free (with its words: no descriptor read); the node side
                   // goes on with the other child or the stack.  A leaf child that finds the leaf side busy waits in `cur`.
+#if WALK_FLAT_CONTROL
+                  // (the same decisions as the branch form below, taken on the children in visiting order -- A first, B second --
+                  // so that every choice is one select deep)
+                  const bool lfree = lf == 0;
+                  const bool both = lok && rok, any = lok || rok;
+                  const bool first_right = rok && (!lok || tr < tl);   // nearest child first; the order never decides WHETHER a child is visited
+                  const int eA = first_right ? re : le, eB = first_right ? le : re;
+                  const int gA = first_right ? rg : lg, gB = first_right ? lg : rg;
+                  const unsigned mA = first_right ? __float_as_uint(q4.w) : __float_as_uint(q4.y), mB = first_right ? __float_as_uint(q4.y) : __float_as_uint(q4.w);
+                  const unsigned tA = first_right ? rtodo : ltodo, tB = first_right ? ltodo : rtodo;
+                  const bool hand_a = any && lfree && eA < 0;              // A goes to the leaf side ...
+                  const bool hand_b = both && lfree && !hand_a && eB < 0;  // ... or B does, and the node side goes on with A
+                  const bool need_pop = !any || (hand_a && !both);
+                  if (both && !hand_a && !hand_b) {
+                     stack[sp * BLOCK_THREADS] = eB;
+                     ++sp;
+                  }
+                  int next = hand_a ? eB : eA;
+                  if (need_pop) {
+                     next = STACK_EMPTY;
+                     if (sp > bot) {
+                        --sp;
+                        next = stack[sp * BLOCK_THREADS];
+                     }
+                  }
+                  cur = next;
+                  wmask = 0u;
+                  if (!need_pop && cur < 0) {   // a leaf child that waits in `cur` keeps its words
+                     wg = hand_a ? gB : gA;
+                     wmask = hand_a ? mB : mA;
+                  }
+                  if (hand_a || hand_b) {
+                     const int g = hand_a ? gA : gB;
+                     lf = hand_a ? eA : eB;
+                     if (((g ^ gb) & DESC_BASE_MASK) != 0) missed = 0u;   // another group
+                     if (STATS > 1) d_repeat += (unsigned) __popc((hand_a ? mA : mB) & missed);
+                     gb = g;
+                     todo = hand_a ? tA : tB;   // 0 only for a leaf that goes on in further descriptors: the leaf step moves on
+                  }
+#else
                   const bool lfree = lf == 0;
                   int hand = 0;   // 1 / 2: the left / right child goes to the leaf side
                   int kept = 0;   // 1 / 2: the left / right child is what `cur` holds now
@@ -1196,6 +1239,7 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                      gb = g;
                      todo = hand == 1 ? ltodo : rtodo;   // 0 only for a leaf that goes on in further descriptors: the leaf step moves on
                   }
+#endif
                }
             }
          }
