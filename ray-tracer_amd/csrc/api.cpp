@@ -502,6 +502,8 @@ void finish_part(ScenePart &part, bool &boxes_finite)
       }
       if (d.llink != LINK_NONE) d.llink += (int32_t) (d.lcnt > 0 ? part.desc_base : part.node_base);
       if (d.rlink != LINK_NONE) d.rlink += (int32_t) (d.rcnt > 0 ? part.desc_base : part.node_base);
+      d.lcnt = d.lcnt > 0 ? -1 : 0;   // the uploaded form keeps "is a leaf" as a mask (layout.h)
+      d.rcnt = d.rcnt > 0 ? -1 : 0;
       for (int side = 0; side < 2; side++)
          boxes_finite = boxes_finite && std::isfinite(d.lo_x[side]) && std::isfinite(d.lo_y[side]) && std::isfinite(d.lo_z[side]) &&
                         std::isfinite(d.hi_x[side]) && std::isfinite(d.hi_y[side]) && std::isfinite(d.hi_z[side]);

@@ -442,6 +442,8 @@ __global__ void leaf_words_kernel(DevNodeRec *recs, unsigned n, const LeafDesc *
       r.rgbase = d.gbase;
       r.rmask = d.mask;
    }
+   r.lcnt = r.lcnt > 0 ? -1 : 0;   // the uploaded form keeps "is a leaf" as a mask (layout.h)
+   r.rcnt = r.rcnt > 0 ? -1 : 0;
 }
 
 // leaf slots in the reference's order: the face id of every (leaf, face) pair, and the first slot of the slot's leaf

@@ -11,13 +11,14 @@
 //             float4 a = { lmin.x, rmin.x, lmin.y, rmin.y }
 //             float4 b = { lmin.z, rmin.z, lmax.x, rmax.x }
 //             float4 c = { lmax.y, rmax.y, lmax.z, rmax.z }
-//             int4   d = { llink, rlink, lcnt, rcnt }
+//             int4   d = { llink, rlink, lleaf, rleaf }
 //             int4   e = { lgbase, lmask, rgbase, rmask }   (leaf children: their descriptors' words, see LEAVES)
 //           The two children's values of one coordinate sit side by side (an aligned register pair after the
 //           128-bit load), so the walker's slab arithmetic runs both children through packed-f32 instructions
 //           (v_pk_add_f32 / v_pk_mul_f32: two results per issue slot).
-//           link: cnt == 0 -> index of the child's node record; cnt > 0 -> index of the first LEAF DESCRIPTOR of a
-//           leaf child holding cnt faces; link == LINK_NONE -> the reference's null child.
+//           link: index of the child's node record, or (leaf == -1; 0 otherwise) of the first LEAF DESCRIPTOR of a leaf
+//           child, so that link ^ leaf is the walker's cursor form at once (a leaf is ~descriptor); link == LINK_NONE ->
+//           the reference's null child.  (While a record is being built the two words hold the children's face counts.)
 //   LEAVES (scene_build.hpp "leaf groups").  The reference's builder copies a face into every leaf whose box it
 //   straddles (KDNode.java:58-69: 6.9 leaf slots per face on the Dragon-class mesh).  Which leaves a ray reaches
 //   decides its answer, so the leaves stay; but a face that a ray misses, it misses in every leaf.  So:
@@ -69,7 +70,7 @@ static_assert(sizeof(NodeRec) == 64, "node record must be 64 bytes");
 // needs no fetch of its own for the descriptor, and a leaf none of whose faces is still untested costs nothing at all
 struct DevNodeRec {   // 80 B = 5 x float4
    float lo_x[2], lo_y[2], lo_z[2], hi_x[2], hi_y[2], hi_z[2];
-   int32_t llink, rlink, lcnt, rcnt;
+   int32_t llink, rlink, lcnt, rcnt;   // (lcnt, rcnt: face counts while the record is built, -1 / 0 "is a leaf" masks as uploaded)
    int32_t lgbase;
    uint32_t lmask;
    int32_t rgbase;

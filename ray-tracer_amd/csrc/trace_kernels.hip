@@ -1129,18 +1129,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                         rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
                      }
                   }
-                  const int le = nd.z > 0 ? ~nd.x : nd.x;
-                  const int re = nd.w > 0 ? ~nd.y : nd.y;
+                  const int le = nd.x ^ nd.z;   // (the record's "is a leaf" masks: a leaf is ~descriptor)
+                  const int re = nd.y ^ nd.w;
                   // what is left to test in a leaf child is known here (the leaf side's group and `missed` only ever grow
                   // while the group stays: a face in `missed` HAS missed this ray, whenever that is asked)
                   const int lg = __float_as_int(q4.x), rg = __float_as_int(q4.z);
                   const unsigned ltodo = __float_as_uint(q4.y) & ~((((lg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
                   const unsigned rtodo = __float_as_uint(q4.w) & ~((((rg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
-                  if (nd.z > 0 && ltodo == 0u && !(lg & DESC_MORE)) {
+                  if (nd.z != 0 && ltodo == 0u && !(lg & DESC_MORE)) {
                      if (STATS > 1 && lok) d_repeat += (unsigned) __popc(__float_as_uint(q4.y));
                      lok = false;
                   }
-                  if (nd.w > 0 && rtodo == 0u && !(rg & DESC_MORE)) {
+                  if (nd.w != 0 && rtodo == 0u && !(rg & DESC_MORE)) {
                      if (STATS > 1 && rok) d_repeat += (unsigned) __popc(__float_as_uint(q4.w));
                      rok = false;
                   }
@@ -1406,18 +1406,18 @@ __global__ __launch_bounds__(BLOCK_THREADS) __attribute__((amdgpu_waves_per_eu(w
                rok = rok && !(origin_box_dist2(r, na.y, na.w, nb.y, nb.w, nc.y, nc.w) > light_far2(light, na.y, na.w, nb.y, nb.w, nc.y, nc.w) * 1.0001f + a.light_prune_c);
             }
          }
-         const int le = nd.z > 0 ? ~nd.x : nd.x;   // stack / cursor form of each child: leaf = ~(its first descriptor)
-         const int re = nd.w > 0 ? ~nd.y : nd.y;
+         const int le = nd.x ^ nd.z;   // stack / cursor form of each child: leaf = ~(its first descriptor); the record's masks
+         const int re = nd.y ^ nd.w;
          // A leaf child's descriptor words ride in this record: what is left to test in it is known here.  A leaf all of
          // whose faces this ray has already missed (in neighbouring leaves of its group) is no visit at all.
          const int lg = __float_as_int(q[4].x), rg = __float_as_int(q[4].z);
          const unsigned ltodo = __float_as_uint(q[4].y) & ~((((lg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
          const unsigned rtodo = __float_as_uint(q[4].w) & ~((((rg ^ gb) & DESC_BASE_MASK) == 0) ? missed : 0u);
-         if (nd.z > 0 && ltodo == 0u && !(lg & DESC_MORE)) {
+         if (nd.z != 0 && ltodo == 0u && !(lg & DESC_MORE)) {
             if (STATS > 1 && lok) d_repeat += (unsigned) __popc(__float_as_uint(q[4].y));
             lok = false;
          }
-         if (nd.w > 0 && rtodo == 0u && !(rg & DESC_MORE)) {
+         if (nd.w != 0 && rtodo == 0u && !(rg & DESC_MORE)) {
             if (STATS > 1 && rok) d_repeat += (unsigned) __popc(__float_as_uint(q[4].w));
             rok = false;
          }
