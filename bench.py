@@ -265,6 +265,8 @@ def main():
                          % (lib_ranks, torch.cuda.device_count(), lib_ranks))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libmi355rt has no CPU path")
+    if args.rehearse_one_gpu and world > 1:
+        local_rank = 0   # (every rank of the rehearsal on the one GPU, also when torch.distributed.run numbered them)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rehearse = args.rehearse_one_gpu and world > 1
