@@ -438,6 +438,10 @@ def main():
                 # launch at 39 % lane use; `frac` above is SURVEY 8(d)'s ALGORITHMIC bytes over time, which L2 hits let exceed
                 # what HBM moves (big-leaf scenes: even 1.0) -- the memory side's own figure is hbm_measured_frac.
                 "limiter": measured.get("limiter"), "valu_busy": measured.get("valu_busy"), "lane_util": measured.get("lane_util"),
+                # (the counters' word; round 3's A/B runs qualify it for the small-leaf walker -- a tenth fewer vector
+                # instructions in its leaf step, a fifth fewer L1 accesses in its node step, its two fetches overlapped: no
+                # gain from any, so no single unit is the limit; L1 0.58 accesses per cycle and CU + 0.34 stalled)
+                "limiter_note": "DESIGN.md section 6; profiles/r03_dragon_l1_counters.txt" if measured.get("limiter") == "valu-issue" and fused else None,
                 "traffic_source": measured.get("source"),
                 # the memory side's own figure, from the PMC counters of profiles/ (per launch, when a profile of this workload
                 # and of these kernel sources is there): what the kernel really moves from HBM -- the rest are L2 / MALL hits
