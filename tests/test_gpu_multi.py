@@ -147,3 +147,59 @@ def test_device_list_errors(rt):
     with pytest.raises(rt._abi.Mi355rtError):
         scene.setDevices([0, 0])   # once per scene
     scene.close()
+
+
+_ONE_RANK_RCCL = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29533")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch
+import torch.distributed as dist
+import ray_tracer_amd as rt
+from ray_tracer_amd import tiles
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+light = rt.Light((0.0, 100.0, 100.0), (0.3, 0.3, 0.3), (0.5, 0.5, 0.9))
+v, i = rt.meshgen.stanford_standin("dragon", 30000)
+mesh = rt.TriangleMesh((v, i), rt.ColorInformation((0.9, 0.9, 0.9)), True)
+scene = rt.Scene([mesh], light, (0, 0, 0), rt.PhongLightingModel(light, [mesh]), 23.0)
+W, H, spp, tile = 648, 400, 2, 16
+cam = rt.Camera(scene, spp, 1, rt.RTStatics.NEAR_PLANE, W, H, rng_seed=3)
+ref = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev), torch.zeros((H, W), dtype=torch.int32, device=dev),
+       torch.zeros((H, W), dtype=torch.int32, device=dev), torch.zeros((H, W), dtype=torch.float32, device=dev)]
+cam.render_device(rt._abi.Frame(ref[0].data_ptr(), None, ref[1].data_ptr(), ref[2].data_ptr(), ref[3].data_ptr()))
+torch.cuda.synchronize()
+sh = tiles.TileSharder(W, H, 0, 1, tile, dev)
+side = torch.cuda.Stream(device=dev)
+for rep in range(3):
+    got = [torch.full_like(t, 7) for t in ref]
+    with torch.cuda.stream(side):
+        cam.render_device(sh.blocks[0].frame(), stream=side.cuda_stream, tile_rank=0, tile_world=1, tile_size=tile, tile_compact=True)
+        # what TileSharder.gather does on rank 0 of N ranks, with N = 1: the block through dist.gather on the RCCL backend
+        # (asynchronous, on a side stream, into slices of one receive area), then the library's unpack kernel
+        recv = torch.empty(tiles.PLANES * sh.n, dtype=torch.float32, device=dev)
+        work = dist.gather(sh.blocks[0].flat, gather_list=list(recv.view(1, -1).unbind(0)), dst=0, async_op=True)
+        work.wait()
+        sh.unpack(recv, *got)
+    side.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), rep
+dist.destroy_process_group()
+scene.close()
+print("one-rank RCCL gather ok")
+'''
+
+
+def test_the_process_per_gpu_gather_over_rccl_with_one_rank():
+    """tiles.TileSharder's exchange as rank 0 runs it -- dist.gather on torch.distributed's "nccl" backend (RCCL), asynchronous,
+    on a side stream, into slices of the receive area, then mi355rt_tiles_unpack_device -- with a process group of ONE rank
+    (all that one GPU allows: RCCL refuses two ranks on a device).  In a process of its own: the group is process-wide."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ONE_RANK_RCCL], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    assert "one-rank RCCL gather ok" in r.stdout
