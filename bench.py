@@ -468,8 +468,8 @@ def main():
             soup = soup_line(rt, args, light, cfg, dev, W, H)
 
     cpu = None
-    if not args.no_cpu_baseline and args.material == "color" and not args.in_library_child:
-        cpu = cpu_baseline(args, verts, idx, normals, cfg, light)
+    if not args.no_cpu_baseline and args.material == "color" and not args.in_library_child and world == 1 and lib_ranks == 1:
+        cpu = cpu_baseline(args, verts, idx, normals, cfg, light)   # (N = 1 only: a reported baseline, timed once per round)
 
     in_library = None
     if world > 1 and not rehearse:
