@@ -199,3 +199,28 @@ def test_trace_rays_arbitrary(rt):
     np.testing.assert_array_equal(g["point"][hit].view(np.uint32), r["point"][hit].view(np.uint32))
     np.testing.assert_array_equal(g["normal"][hit].view(np.uint32), r["normal"][hit].view(np.uint32))
     pair.close()
+
+
+def test_sixty_four_objects_and_one_too_many(rt):
+    """MAX_OBJECTS meshes in one scene (the walker's object index fields are 7 bits wide: layout.h) -- an 8 x 8 grid of small
+    blobs, every one its own hierarchy, colour and root box, one of them a mirror -- against the oracle; a 65th is refused
+    with MI355RT_E_LIMIT before anything is built."""
+    from helpers import Pair
+    objs = []
+    for k in range(64):
+        v, i = rt.meshgen.blob(300 + 20 * (k % 5), span=0.02, seed=100 + k)
+        v = v + np.array([0.03 * (k % 8 - 3.5), 0.03 * (k // 8 - 3.5), 0.005 * (k % 3)], dtype=np.float32)
+        mat = rt.ReflectionMaterial((0.9, 0.9, 1.0)) if k == 27 else rt.ColorInformation((0.3 + 0.01 * k, 1.0 - 0.01 * k, 0.5))
+        objs.append((v.astype(np.float32), i, None, mat))
+    pair = Pair(objs, orientation=(0, 10, 0), fov=25.0)
+    hit_frac = _check(pair, 160, 120, ms=2, seed=9)
+    assert hit_frac > 0.2
+    cam, ocam, ost = pair.cameras(160, 120, ms=1)
+    cam.createImage()
+    assert len(np.unique(cam.hit_obj[cam.hit_obj >= 0])) >= 60   # (nearly) every object is seen
+    pair.close()
+    light = rt.Light()
+    meshes = [rt.TriangleMesh(rt.meshgen.blob(60, span=0.01, seed=k), rt.ColorInformation((1, 1, 1)), True) for k in range(65)]
+    with pytest.raises(rt._abi.Mi355rtError) as e:
+        rt.Scene(meshes, light, (0, 0, 0), rt.LightingModel(), 15.0)
+    assert "64" in str(e.value)
