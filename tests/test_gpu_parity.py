@@ -224,3 +224,11 @@ def test_sixty_four_objects_and_one_too_many(rt):
     with pytest.raises(rt._abi.Mi355rtError) as e:
         rt.Scene(meshes, light, (0, 0, 0), rt.LightingModel(), 15.0)
     assert "64" in str(e.value)
+
+
+@pytest.mark.parametrize("W,H,ms", [(1, 1, 1), (1, 9, 3), (9, 1, 2), (3, 2, 5), (17, 1, 1), (8, 8, 33)])
+def test_smallest_and_thinnest_images(rt, W, H, ms):
+    """Images of one pixel, one row, one column (every 8 x 8 pixel group ragged) and a sample count far above the usual."""
+    pair = _blob_pair(rt, 2000)
+    _check(pair, W, H, ms=ms, seed=4)
+    pair.close()
